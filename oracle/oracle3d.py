@@ -1,0 +1,181 @@
+"""ctypes binding of the CPU oracle (oracle/fluid3d_oracle.c).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py may import this module.  The shipped library never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+FLUID, OBJECT, STATIC = 0, 1, 2
+U, V, W, D, SU, SV, SW, SD = range(8)
+
+
+def build():
+    """Compile the oracle libraries (gcc, seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def _lib(dtype):
+    name = {np.float32: "f32", np.float64: "f64"}[dtype]
+    if name in _LIBS:
+        return _LIBS[name]
+    path = os.path.join(_HERE, f"libfluid3d_oracle_{name}.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    real = C.c_float if dtype is np.float32 else C.c_double
+    P = C.c_void_p
+    lib.o3_create.restype = P
+    lib.o3_create.argtypes = [C.c_int] * 3
+    lib.o3_destroy.argtypes = [P]
+    lib.o3_field.restype = P
+    lib.o3_field.argtypes = [P, C.c_int]
+    lib.o3_cells.restype = P
+    lib.o3_cells.argtypes = [P]
+    lib.o3_sphere_emitter.argtypes = [P] + [C.c_float] * 5
+    lib.o3_sphere_influence.argtypes = [P, C.c_float]
+    lib.o3_fill_sphere.argtypes = [P] + [C.c_float] * 4 + [C.c_int]
+    lib.o3_fill_sphere_influence.argtypes = [P, C.c_float, C.c_int]
+    lib.o3_bottom_influence.argtypes = [P]
+    lib.o3_clear.argtypes = [P]
+    lib.o3_gs_lexi.restype = real
+    lib.o3_gs_lexi.argtypes = [P]
+    lib.o3_semi_lagrange.argtypes = [P, real, P, P, P, P]
+    lib.o3_update.restype = C.c_int
+    lib.o3_update.argtypes = [P, real, real, C.c_int, C.POINTER(real)]
+    lib.o3_rb_halfsweep.argtypes = [P, C.c_int, real]
+    lib.o3_rb_sweep.restype = C.c_double
+    lib.o3_rb_sweep.argtypes = [P, real]
+    lib.o3_div_sumsq.restype = C.c_double
+    lib.o3_div_sumsq.argtypes = [P, C.POINTER(C.c_double)]
+    lib.o3_residual_l2.restype = C.c_double
+    lib.o3_residual_l2.argtypes = [P]
+    lib.o3_advect.argtypes = [P, real] + [P] * 11 + [C.c_int]
+    lib.o3_reflect.argtypes = [C.c_int64, P, P, P]
+    lib.o3_buoyancy.argtypes = [P, real]
+    lib.o3_project_rb.restype = C.c_int
+    lib.o3_project_rb.argtypes = [P, real, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib._real = real
+    _LIBS[name] = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle3D:
+    """The reference's 3D FluidSim (advection-reflection/main.cpp:21-442), restated on the CPU."""
+
+    def __init__(self, nx, ny, nz, dtype=np.float32):
+        self.dtype = dtype
+        self.lib = _lib(dtype)
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.h = self.lib.o3_create(nx, ny, nz)
+        self.n = nx * ny * nz
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.o3_destroy(self.h)
+            self.h = None
+
+    # --- state views (zero-copy numpy views onto the C arrays, shape (nz, ny, nx)) ---
+    def field(self, which):
+        p = self.lib.o3_field(self.h, which)
+        ct = C.c_float if self.dtype is np.float32 else C.c_double
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(self.n,))
+        return arr.reshape(self.nz, self.ny, self.nx)
+
+    @property
+    def u(self): return self.field(U)
+    @property
+    def v(self): return self.field(V)
+    @property
+    def w(self): return self.field(W)
+    @property
+    def d(self): return self.field(D)
+
+    @property
+    def cells(self):
+        p = self.lib.o3_cells(self.h)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n,))
+        return arr.reshape(self.nz, self.ny, self.nx)
+
+    # --- reference surface ---
+    def sphere_influence(self, radius):
+        self.lib.o3_sphere_influence(self.h, radius)
+
+    def sphere_emitter(self, radius, cx, cy, cz, strength):
+        self.lib.o3_sphere_emitter(self.h, radius, cx, cy, cz, strength)
+
+    def fill_sphere_influence(self, radius, it):
+        self.lib.o3_fill_sphere_influence(self.h, radius, it)
+
+    def fill_sphere(self, radius, cx, cy, cz, it):
+        self.lib.o3_fill_sphere(self.h, radius, cx, cy, cz, it)
+
+    def bottom_influence(self):
+        self.lib.o3_bottom_influence(self.h)
+
+    def clear(self):
+        self.lib.o3_clear(self.h)
+
+    def gauss_seidel_projection(self):
+        return float(self.lib.o3_gs_lexi(self.h))
+
+    def semi_lagrange(self, dt):
+        """Self-advection from a fresh snapshot, as update() does (main.cpp:122-129)."""
+        for a, b in ((SU, U), (SV, V), (SW, W), (SD, D)):
+            self.field(a)[...] = self.field(b)
+        f = lambda k: self.lib.o3_field(self.h, k)
+        self.lib.o3_semi_lagrange(self.h, dt, f(SU), f(SV), f(SW), f(SD))
+
+    def update(self, dt, change_tol=5.0, max_iter=1000):
+        last = self.lib._real(0)
+        it = self.lib.o3_update(self.h, dt, change_tol, max_iter, C.byref(last))
+        return it, float(last.value)
+
+    # --- extensions ---
+    def rb_halfsweep(self, colour, omega=1.0):
+        self.lib.o3_rb_halfsweep(self.h, colour, omega)
+
+    def rb_sweep(self, omega=1.0):
+        return float(self.lib.o3_rb_sweep(self.h, omega))
+
+    def div_sumsq(self):
+        mx = C.c_double(0)
+        s = self.lib.o3_div_sumsq(self.h, C.byref(mx))
+        return float(s), float(mx.value)
+
+    def residual_l2(self):
+        return float(self.lib.o3_residual_l2(self.h))
+
+    def project_rb(self, omega=1.0, stop_mode=0, tol=0.0, max_iter=100, check_every=1):
+        m = C.c_double(0)
+        it = self.lib.o3_project_rb(self.h, omega, stop_mode, tol, max_iter, check_every, C.byref(m))
+        return it, float(m.value)
+
+    def advect(self, dt, q, vel, density_mode):
+        """q = (qu,qv,qw,qd), vel = (U,V,W) numpy arrays; returns the four advected arrays."""
+        q = [np.ascontiguousarray(a, dtype=self.dtype) for a in q]
+        vel = [np.ascontiguousarray(a, dtype=self.dtype) for a in vel]
+        out = [np.empty_like(q[0]) for _ in range(4)]
+        self.lib.o3_advect(self.h, dt, *[_ptr(a) for a in q], *[_ptr(a) for a in vel],
+                           *[_ptr(a) for a in out], density_mode)
+        return out
+
+    def reflect(self, proj, tilde):
+        proj = np.ascontiguousarray(proj, dtype=self.dtype)
+        tilde = np.ascontiguousarray(tilde, dtype=self.dtype)
+        out = np.empty_like(proj)
+        self.lib.o3_reflect(proj.size, _ptr(proj), _ptr(tilde), _ptr(out))
+        return out
+
+    def buoyancy(self, dt):
+        self.lib.o3_buoyancy(self.h, dt)

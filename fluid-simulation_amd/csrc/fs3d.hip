@@ -1,0 +1,1043 @@
+// C ABI of the 3D fluid step (include/fluidsim_amd.h): host logic that owns the
+// device state, launches the kernels of fs_kernels3d.hpp on the handle's
+// stream and moves halo planes between z-slabs.
+//
+// State layout in HBM.  The global nx*ny*nz grid is cut along z (the slowest
+// axis, so a slab is one contiguous range of planes) into P = nranks *
+// local_slabs parts.  A part holds its owned planes plus H halo planes on
+// either side when P > 1 (H = 2: one plane for the stencil, one for a
+// backtrace of up to two cells), as dense x-fastest arrays:
+//   f[2][4]   u, v, w, density -- two generations; advection writes the other
+//             generation and the roles swap, which replaces the reference's
+//             snapshot copies (main.cpp:122-127);
+//   tmp[3]    the unprojected half-step velocity of the reflection step, also
+//             the divergence output;
+//   cells     the reference's m_s as one byte per cell; flags = the neighbour
+//             bits derived from it.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "fs_comm.hpp"
+#include "fs_common.hpp"
+#include "fs_kernels3d.hpp"
+
+using namespace fsamd;
+
+namespace {
+
+constexpr int kReduceBlocks = 1024;
+
+struct Part {
+    Grid g{};
+    int z0 = 0, z1 = 0;   // owned planes, global
+    int H = 0;            // halo planes on either side
+    int zb = 0, ze = 0;   // local range of the interior planes this part relaxes / advects
+    int gp = 0;           // global part index
+    bool has_lo = false, has_hi = false;
+    size_t n = 0;         // local element count
+    void* f[2][4] = {{nullptr}};
+    void* tmp[3] = {nullptr};
+    uint8_t* cells = nullptr;
+    uint8_t* flags = nullptr;
+    void* recv_lo = nullptr;   // staging for the interface w plane from the lower / upper rank
+    void* recv_hi = nullptr;
+    double* partials = nullptr;
+    int own_planes() const { return z1 - z0; }
+};
+
+}  // namespace
+
+struct fs3d_sim {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fs3d_config cfg{};
+    int nx = 0, ny = 0, nz = 0;
+    size_t esz = 4;
+    int rank = 0, nranks = 1, nlocal = 1, nparts_global = 1;
+    std::vector<Part> parts;
+    int cur = 0;                 // generation holding the current state
+    bool cells_dirty = true, halo_dirty = true;
+    double* dres = nullptr;      // 2 doubles per local part + 2 combined
+    double* hres = nullptr;      // pinned mirror of the combined pair
+    int* doob = nullptr;         // device flag: a backtrace left the slab's halo
+    int* hoob = nullptr;
+    ncclComm_t comm = nullptr;
+    Rccl* rccl = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    fs3d_stats stats{};
+    double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
+    std::string err;
+};
+
+namespace {
+
+template <typename T> T* F(Part& p, int gen, int k) { return (T*)p.f[gen][k]; }
+
+int set_err(fs3d_sim* s, int code, const std::string& msg) { s->err = msg; return code; }
+
+#define SIM_HIP(call) FS_HIP(s->err, call)
+#define SIM_GUARD(s)                                                                \
+    if (!(s)) return FS_EINVAL;                                                     \
+    DeviceGuard guard__((s)->device);                                               \
+    if (!guard__.ok) return set_err((s), FS_EHIP, "hipSetDevice failed")
+
+int nccl_check(fs3d_sim* s, ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return FS_OK;
+    return set_err(s, FS_ECOMM, std::string(what) + ": " + s->rccl->GetErrorString(r));
+}
+
+void split_planes(int nz, int P, int gp, int* z0, int* z1) {
+    const int base = nz / P, rem = nz % P;
+    *z0 = gp * base + std::min(gp, rem);
+    *z1 = *z0 + base + (gp < rem ? 1 : 0);
+}
+
+void free_parts(fs3d_sim* s) {
+    for (Part& p : s->parts) {
+        for (int g = 0; g < 2; ++g)
+            for (int k = 0; k < 4; ++k) (void)hipFree(p.f[g][k]);
+        for (int k = 0; k < 3; ++k) (void)hipFree(p.tmp[k]);
+        (void)hipFree(p.cells); (void)hipFree(p.flags);
+        (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
+        (void)hipFree(p.partials);
+    }
+    s->parts.clear();
+}
+
+int alloc_parts(fs3d_sim* s) {
+    const int P = s->nparts_global;
+    s->parts.resize(s->nlocal);
+    for (int k = 0; k < s->nlocal; ++k) {
+        Part& p = s->parts[k];
+        p.gp = s->rank * s->nlocal + k;
+        split_planes(s->nz, P, p.gp, &p.z0, &p.z1);
+        p.H = P > 1 ? 2 : 0;
+        p.has_lo = p.gp > 0;
+        p.has_hi = p.gp < P - 1;
+        if (P > 1 && p.own_planes() < p.H)
+            return set_err(s, FS_EINVAL, "too many slabs: every slab needs at least 2 planes");
+        p.g.nx = s->nx; p.g.ny = s->ny; p.g.nzl = p.own_planes() + 2 * p.H;
+        p.g.gz0 = p.z0 - p.H; p.g.gnz = s->nz;
+        p.g.sy = s->nx; p.g.sz = (int64_t)s->nx * s->ny;
+        p.zb = std::max(p.z0, 1) - p.g.gz0;
+        p.ze = std::min(p.z1, s->nz - 1) - p.g.gz0;
+        if (p.ze < p.zb) p.ze = p.zb;
+        p.n = (size_t)p.g.sz * p.g.nzl;
+        for (int g = 0; g < 2; ++g)
+            for (int q = 0; q < 4; ++q) SIM_HIP(hipMalloc(&p.f[g][q], p.n * s->esz));
+        for (int q = 0; q < 3; ++q) SIM_HIP(hipMalloc(&p.tmp[q], p.n * s->esz));
+        SIM_HIP(hipMalloc((void**)&p.cells, p.n));
+        SIM_HIP(hipMalloc((void**)&p.flags, p.n));
+        SIM_HIP(hipMalloc((void**)&p.partials, sizeof(double) * 2 * kReduceBlocks));
+        if (p.H) {
+            SIM_HIP(hipMalloc(&p.recv_lo, (size_t)p.g.sz * s->esz));
+            SIM_HIP(hipMalloc(&p.recv_hi, (size_t)p.g.sz * s->esz));
+        }
+    }
+    return FS_OK;
+}
+
+// ---- cell types ----------------------------------------------------------
+// FluidSim::FluidSim (main.cpp:28-33): shell = Object, rest Fluid.  Planes of a
+// halo that lie outside the global grid are Object as well.
+int init_cells(fs3d_sim* s) {
+    for (Part& p : s->parts) {
+        std::vector<uint8_t> h(p.n);
+        for (int lz = 0; lz < p.g.nzl; ++lz) {
+            const int gz = lz + p.g.gz0;
+            for (int y = 0; y < s->ny; ++y)
+                for (int x = 0; x < s->nx; ++x) {
+                    const bool shell = gz <= 0 || gz >= s->nz - 1 || y == 0 || y == s->ny - 1 || x == 0 ||
+                                       x == s->nx - 1;
+                    h[(size_t)lz * p.g.sz + (size_t)y * s->nx + x] = shell ? FS_CELL_OBJECT : FS_CELL_FLUID;
+                }
+        }
+        SIM_HIP(hipMemcpy(p.cells, h.data(), p.n, hipMemcpyHostToDevice));
+    }
+    s->cells_dirty = true;
+    return FS_OK;
+}
+
+int zero_fields(fs3d_sim* s) {
+    for (Part& p : s->parts) {
+        for (int g = 0; g < 2; ++g)
+            for (int q = 0; q < 4; ++q) SIM_HIP(hipMemsetAsync(p.f[g][q], 0, p.n * s->esz, s->stream));
+        for (int q = 0; q < 3; ++q) SIM_HIP(hipMemsetAsync(p.tmp[q], 0, p.n * s->esz, s->stream));
+    }
+    return FS_OK;
+}
+
+// ---- halo transport -------------------------------------------------------
+// Copies `planes` planes of `bytes_per_plane` bytes between neighbouring parts:
+// from local plane src_lz of part a into local plane dst_lz of part b, for
+// every interface, in both directions.  Parts in this process copy device to
+// device on the stream; parts of another rank go through ncclSend/ncclRecv.
+struct HaloOp {
+    // array selector: returns the base pointer of the array in part p
+    void* (*base)(fs3d_sim*, Part&, int) = nullptr;
+    int which = 0;
+    size_t elem = 1;
+};
+
+int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops) {
+    if (s->nparts_global == 1) return FS_OK;
+    bool remote = false;
+    for (Part& p : s->parts) {
+        const size_t H = p.H;
+        for (const HaloOp& op : ops) {
+            const size_t plane = (size_t)p.g.sz * op.elem;
+            char* mine = (char*)op.base(s, p, op.which);
+            // upper neighbour in this process: fill its low halo from my top owned planes, and my
+            // high halo from its first owned planes
+            if (p.has_hi && (&p != &s->parts.back())) {
+                Part& q = *(&p + 1);
+                char* theirs = (char*)op.base(s, q, op.which);
+                SIM_HIP(hipMemcpyAsync(theirs, mine + (size_t)p.own_planes() * plane, H * plane,
+                                       hipMemcpyDeviceToDevice, s->stream));
+                SIM_HIP(hipMemcpyAsync(mine + (H + p.own_planes()) * plane, theirs + H * plane, H * plane,
+                                       hipMemcpyDeviceToDevice, s->stream));
+            }
+        }
+        if ((p.has_lo && &p == &s->parts.front()) || (p.has_hi && &p == &s->parts.back())) remote = true;
+    }
+    if (!remote || s->nranks == 1) return FS_OK;
+    Rccl* R = s->rccl;
+    FS_TRY(nccl_check(s, R->GroupStart(), "ncclGroupStart"));
+    for (const HaloOp& op : ops) {
+        Part& lo = s->parts.front();
+        Part& hi = s->parts.back();
+        if (lo.has_lo) {
+            const size_t plane = (size_t)lo.g.sz * op.elem, H = lo.H;
+            char* a = (char*)op.base(s, lo, op.which);
+            FS_TRY(nccl_check(s, R->Send(a + H * plane, H * plane, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a, H * plane, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclRecv"));
+        }
+        if (hi.has_hi) {
+            const size_t plane = (size_t)hi.g.sz * op.elem, H = hi.H;
+            char* a = (char*)op.base(s, hi, op.which);
+            FS_TRY(nccl_check(s, R->Send(a + (size_t)hi.own_planes() * plane, H * plane, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a + (H + hi.own_planes()) * plane, H * plane, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclRecv"));
+        }
+    }
+    return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
+}
+
+void* base_field_cur(fs3d_sim* s, Part& p, int k) { return p.f[s->cur][k]; }
+void* base_tmp(fs3d_sim*, Part& p, int k) { return p.tmp[k]; }
+void* base_cells(fs3d_sim*, Part& p, int) { return p.cells; }
+
+int exchange_state_halos(fs3d_sim* s) {
+    std::vector<HaloOp> ops;
+    for (int k = 0; k < 4; ++k) ops.push_back({base_field_cur, k, s->esz});
+    FS_TRY(exchange_halos(s, ops));
+    s->halo_dirty = false;
+    return FS_OK;
+}
+
+int refresh_flags(fs3d_sim* s) {
+    if (!s->cells_dirty) return FS_OK;
+    FS_TRY(exchange_halos(s, {{base_cells, 0, 1}}));
+    for (Part& p : s->parts) {
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
+        hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, p.g, p.cells, p.flags);
+    }
+    SIM_HIP(hipGetLastError());
+    s->cells_dirty = false;
+    return FS_OK;
+}
+
+// Everything a compute entry point needs before its first kernel.
+int prepare(fs3d_sim* s) {
+    FS_TRY(refresh_flags(s));
+    if (s->halo_dirty) FS_TRY(exchange_state_halos(s));
+    return FS_OK;
+}
+
+// ---- projection -----------------------------------------------------------
+// After a half-sweep of colour c the slab below an interface holds the fresh w
+// where the cell under the interface has colour c, the slab above where the
+// cell over it has; each takes the other half from its neighbour.
+template <typename T>
+int exchange_w_interfaces(fs3d_sim* s, int colour) {
+    if (s->nparts_global == 1) return FS_OK;
+    dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), 1);
+    // interfaces inside this process: read the neighbour's plane directly
+    for (size_t k = 0; k + 1 < s->parts.size(); ++k) {
+        Part& lo = s->parts[k];
+        Part& hi = s->parts[k + 1];
+        const int lz_lo = lo.H + lo.own_planes(), lz_hi = hi.H;
+        T* wl = F<T>(lo, s->cur, 2);
+        T* wh = F<T>(hi, s->cur, 2);
+        // the cell over the interface (global plane z1 of `lo`) has parity (x+y+z1); the upper slab
+        // updated the locations of parity == colour, the lower slab the others
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, lo.g, wl, wh + (size_t)lz_hi * hi.g.sz, lz_lo, colour);
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, hi.g, wh, wl + (size_t)lz_lo * lo.g.sz, lz_hi, colour ^ 1);
+    }
+    if (s->nranks == 1) { SIM_HIP(hipGetLastError()); return FS_OK; }
+    Rccl* R = s->rccl;
+    Part& first = s->parts.front();
+    Part& last = s->parts.back();
+    const size_t bytes = (size_t)first.g.sz * s->esz;
+    FS_TRY(nccl_check(s, R->GroupStart(), "ncclGroupStart"));
+    if (first.has_lo) {
+        T* w = F<T>(first, s->cur, 2) + (size_t)first.H * first.g.sz;
+        FS_TRY(nccl_check(s, R->Send(w, bytes, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclSend"));
+        FS_TRY(nccl_check(s, R->Recv(first.recv_lo, bytes, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclRecv"));
+    }
+    if (last.has_hi) {
+        T* w = F<T>(last, s->cur, 2) + (size_t)(last.H + last.own_planes()) * last.g.sz;
+        FS_TRY(nccl_check(s, R->Send(w, bytes, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclSend"));
+        FS_TRY(nccl_check(s, R->Recv(last.recv_hi, bytes, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclRecv"));
+    }
+    FS_TRY(nccl_check(s, R->GroupEnd(), "ncclGroupEnd"));
+    if (first.has_lo)   // I am the upper slab of this interface: take what the lower slab updated
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, first.g, F<T>(first, s->cur, 2), (const T*)first.recv_lo, first.H, colour ^ 1);
+    if (last.has_hi)
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, last.g, F<T>(last, s->cur, 2), (const T*)last.recv_hi, last.H + last.own_planes(), colour);
+    SIM_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+template <typename T>
+int launch_halfsweep(fs3d_sim* s, int colour) {
+    const T omega = (T)s->cfg.omega;
+    for (Part& p : s->parts) {
+        if (p.ze - p.zb <= 0) continue;
+        dim3 b(64, 4, 1), g(div_up(div_up(s->nx - 2, 2), 64), div_up(s->ny - 2, 4), p.ze - p.zb);
+        hipLaunchKernelGGL(k_rb_halfsweep<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
+                           F<T>(p, s->cur, 2), p.flags, colour, omega, p.zb, p.ze);
+    }
+    SIM_HIP(hipGetLastError());
+    return exchange_w_interfaces<T>(s, colour);
+}
+
+template <typename T>
+int sweep_once(fs3d_sim* s) {
+    if (s->cfg.ordering == FS_ORDER_RED_BLACK) {
+        FS_TRY(launch_halfsweep<T>(s, 0));
+        return launch_halfsweep<T>(s, 1);
+    }
+    // lexicographic order as hyperplane wavefronts (single part only)
+    Part& p = s->parts[0];
+    const T omega = (T)s->cfg.omega;
+    dim3 b(64, 4, 1), g(div_up(s->ny - 2, 64), div_up(s->nz - 2, 4), 1);
+    for (int k = 3; k <= (s->nx - 2) + (s->ny - 2) + (s->nz - 2); ++k)
+        hipLaunchKernelGGL(k_lexi_hyperplane<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
+                           F<T>(p, s->cur, 2), p.flags, k, omega);
+    SIM_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+// Combines the per-part (sum, max) pairs, across ranks too, into host values.
+__global__ void k_combine_parts(const double* __restrict__ dres, int nparts, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double sum = 0, mx = 0;
+        for (int k = 0; k < nparts; ++k) { sum += dres[2 * k]; mx = fmax(mx, dres[2 * k + 1]); }
+        out[0] = sum; out[1] = mx;
+    }
+}
+
+int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
+    double* comb = s->dres + 2 * s->nlocal;
+    hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
+    SIM_HIP(hipGetLastError());
+    if (s->nranks > 1) {
+        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm, s->stream), "ncclAllReduce"));
+        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
+    }
+    SIM_HIP(hipMemcpyAsync(s->hres, comb, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    if (sum) *sum = s->hres[0];
+    if (mx) *mx = s->hres[1];
+    return FS_OK;
+}
+
+template <typename T>
+int snapshot_velocity(fs3d_sim* s) {   // main.cpp:192-196; the other generation serves as the snapshot
+    for (Part& p : s->parts)
+        for (int k = 0; k < 3; ++k)
+            SIM_HIP(hipMemcpyAsync(p.f[s->cur ^ 1][k], p.f[s->cur][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+    return FS_OK;
+}
+
+template <typename T>
+int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
+    if (s->cfg.ordering == FS_ORDER_LEXICOGRAPHIC) {
+        Part& p = s->parts[0];
+        hipLaunchKernelGGL(k_change_serial<T>, dim3(1), dim3(64), 0, s->stream, p.g, F<T>(p, s->cur ^ 1, 0),
+                           F<T>(p, s->cur ^ 1, 1), F<T>(p, s->cur ^ 1, 2), F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
+                           F<T>(p, s->cur, 2), s->dres);
+        SIM_HIP(hipGetLastError());
+        SIM_HIP(hipMemcpyAsync(s->hres, s->dres, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        SIM_HIP(hipStreamSynchronize(s->stream));
+        *change = s->hres[0];
+        return FS_OK;
+    }
+    for (int k = 0; k < s->nlocal; ++k) {
+        Part& p = s->parts[k];
+        hipLaunchKernelGGL(k_change_l1<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->cur ^ 1, 0),
+                           F<T>(p, s->cur ^ 1, 1), F<T>(p, s->cur ^ 1, 2), F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
+                           F<T>(p, s->cur, 2), p.zb, p.ze, p.partials);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
+    }
+    SIM_HIP(hipGetLastError());
+    return finish_reduction(s, change, nullptr);
+}
+
+template <typename T>
+int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
+    for (int k = 0; k < s->nlocal; ++k) {
+        Part& p = s->parts[k];
+        hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->cur, 0),
+                           F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), p.flags, p.zb, p.ze, p.partials,
+                           store_div ? (T*)p.tmp[0] : (T*)nullptr);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
+    }
+    SIM_HIP(hipGetLastError());
+    double sum = 0, mx = 0;
+    FS_TRY(finish_reduction(s, &sum, &mx));
+    const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
+    if (l2) *l2 = sqrt(sum) / ninterior;   // 3_fluid/FluidSim.cpp:40-43
+    if (max_abs) *max_abs = mx;
+    return FS_OK;
+}
+
+// One sweep with the reference's change metric (main.cpp:189-254).
+template <typename T>
+int sweep_with_change(fs3d_sim* s, double* change) {
+    FS_TRY(snapshot_velocity<T>(s));
+    FS_TRY(sweep_once<T>(s));
+    return change_since_snapshot<T>(s, change);
+}
+
+// The loop of update() (main.cpp:105-111) under the configured stopping rule.
+template <typename T>
+int project(fs3d_sim* s, int* sweeps_out, double* metric_out) {
+    FS_TRY(prepare(s));
+    const fs3d_config& c = s->cfg;
+    const int every = std::max(1, c.check_every);
+    int it = 0;
+    double metric = 0;
+    for (;;) {
+        const bool check = ((it + 1) % every == 0) || (it + 1 >= c.max_iters);
+        if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
+            FS_TRY(sweep_with_change<T>(s, &metric));
+        } else {
+            FS_TRY(sweep_once<T>(s));
+        }
+        ++it;
+        if (c.stop_mode == FS_STOP_L1_CHANGE && check && !(metric > c.tol)) break;
+        if (c.stop_mode == FS_STOP_L2_RESIDUAL && check) {
+            FS_TRY(residual<T>(s, &metric, nullptr, false));
+            metric /= s->resid_dt;   // b = -div/dt (3_fluid/FluidSim.cpp:17), dx = rho = 1
+            if (!(metric > c.tol)) break;
+        }
+        if (it >= c.max_iters) break;
+    }
+    s->stats.sweeps = it;
+    s->stats.sweeps_step += it;
+    s->stats.metric = metric;
+    s->halo_dirty = s->nparts_global > 1;   // only the interface w plane was kept current
+    if (sweeps_out) *sweeps_out = it;
+    if (metric_out) *metric_out = metric;
+    return FS_OK;
+}
+
+// ---- advection / reflection ------------------------------------------------
+// Carries q = (qu,qv,qw from `qsrc`, density of the current generation) along the current
+// generation's velocity into the other generation, then swaps generations.
+template <typename T>
+int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode) {
+    FS_TRY(prepare(s));
+    if (s->nparts_global > 1) {
+        FS_TRY(exchange_state_halos(s));
+        if (q_from_tmp) FS_TRY(exchange_halos(s, {{base_tmp, 0, s->esz}, {base_tmp, 1, s->esz}, {base_tmp, 2, s->esz}}));
+    }
+    SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
+    const int c = s->cur, o = s->cur ^ 1;
+    for (Part& p : s->parts) {
+        // the owned planes, shell included, so that the new generation is complete
+        const int zb = p.H, ze = p.H + p.own_planes();
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
+        const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, c, 0);
+        const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, c, 1);
+        const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, c, 2);
+        hipLaunchKernelGGL(k_advect<T>, g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, c, 3), F<T>(p, c, 0), F<T>(p, c, 1),
+                           F<T>(p, c, 2), F<T>(p, o, 0), F<T>(p, o, 1), F<T>(p, o, 2), F<T>(p, o, 3), p.flags, (T)t_step,
+                           density_mode, zb, ze, s->doob);
+    }
+    SIM_HIP(hipGetLastError());
+    s->cur = o;
+    s->halo_dirty = s->nparts_global > 1;
+    if (s->nparts_global > 1) {   // a backtrace beyond the halo cannot be served: report it
+        SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        SIM_HIP(hipStreamSynchronize(s->stream));
+        if (*s->hoob) return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells)");
+    }
+    return FS_OK;
+}
+
+template <typename T>
+int buoyancy(fs3d_sim* s, double dt) {
+    FS_TRY(prepare(s));
+    for (Part& p : s->parts) {
+        if (p.ze - p.zb <= 0) continue;
+        dim3 b(64, 4, 1), g(div_up(s->nx - 2, 64), div_up(s->ny - 2, 4), p.ze - p.zb);
+        hipLaunchKernelGGL(k_buoyancy<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 1), F<T>(p, s->cur, 3), p.flags, (T)dt,
+                           (T)(0.1 * s->cfg.buoyancy), p.zb, p.ze);
+    }
+    SIM_HIP(hipGetLastError());
+    s->halo_dirty = s->nparts_global > 1;
+    return FS_OK;
+}
+
+template <typename T>
+int step(fs3d_sim* s, double dt) {
+    s->stats.sweeps_step = 0;
+    s->resid_dt = dt > 0 ? dt : 1.0;
+    SIM_HIP(hipEventRecord(s->ev[0], s->stream));
+    if (s->cfg.buoyancy != 0.0) FS_TRY(buoyancy<T>(s, dt));
+    if (s->cfg.step_mode == FS_STEP_REFERENCE) {
+        // FluidSim::update (main.cpp:102-130)
+        FS_TRY(project<T>(s, nullptr, nullptr));
+        SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+        FS_TRY(advect<T>(s, dt, false, 1));
+        SIM_HIP(hipEventRecord(s->ev[2], s->stream));
+        SIM_HIP(hipEventRecord(s->ev[3], s->stream));
+    } else {
+        // Advection-reflection, phase-shifted to the reference's convention of projecting first and
+        // leaving the advected field for the next step to project:
+        //   u0 = P(state); ut = A(u0; u0, dt/2); uh = P(ut); ur = 2 uh - ut; state = A(ur; uh, dt/2)
+        FS_TRY(project<T>(s, nullptr, nullptr));
+        FS_TRY(advect<T>(s, 0.5 * dt, false, 0));
+        for (Part& p : s->parts)
+            for (int k = 0; k < 3; ++k)
+                SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->cur][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+        FS_TRY(project<T>(s, nullptr, nullptr));
+        SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+        for (Part& p : s->parts)
+            hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->cur, 0),
+                               F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
+                               (const T*)p.tmp[2], (T*)p.tmp[0], (T*)p.tmp[1], (T*)p.tmp[2]);
+        SIM_HIP(hipGetLastError());
+        FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
+        SIM_HIP(hipEventRecord(s->ev[2], s->stream));
+        SIM_HIP(hipEventRecord(s->ev[3], s->stream));
+    }
+    s->stats.time += dt;
+    s->stats.step += 1;
+    return FS_OK;
+}
+
+#define DISPATCH(s, fn, ...) ((s)->cfg.dtype == FS_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+// ---- host <-> device field access -----------------------------------------
+// Plane range addressed by set/get: the whole grid on a single rank, this
+// rank's owned planes otherwise.
+void owned_range(const fs3d_sim* s, int* z0, int* z1) {
+    *z0 = s->parts.front().z0;
+    *z1 = s->parts.back().z1;
+}
+
+void* field_ptr(fs3d_sim* s, Part& p, int which) {
+    if (which >= FS_FIELD_U && which <= FS_FIELD_DENSITY) return p.f[s->cur][which];
+    return p.tmp[0];
+}
+
+// ---- scene helpers ----------------------------------------------------------
+struct Stamp { std::vector<int64_t> idx; std::vector<float> val; };
+
+// Cells of the sphere (main.cpp:46-52) that fall into a part's local array, with their weights.
+void sphere_cells(const fs3d_sim* s, const Part& p, float radius, float cx, float cy, float cz, Stamp* out) {
+    const float r2 = powf(radius, 2.0f);
+    auto lo = [](float c, float r) { return (int)floorf(c - r) - 1; };
+    auto hi = [](float c, float r) { return (int)ceilf(c + r) + 1; };
+    const int x0 = std::max(1, lo(cx, radius)), x1 = std::min(s->nx - 2, hi(cx, radius));
+    const int y0 = std::max(1, lo(cy, radius)), y1 = std::min(s->ny - 2, hi(cy, radius));
+    const int z0 = std::max(1, lo(cz, radius)), z1 = std::min(s->nz - 2, hi(cz, radius));
+    for (int z = z0; z <= z1; ++z) {
+        const int lz = z - p.g.gz0;
+        if (lz < 0 || lz >= p.g.nzl) continue;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const float xc = x - cx, yc = y - cy, zc = z - cz;
+                const float dist = powf(xc, 2.0f) + powf(yc, 2.0f) + powf(zc, 2.0f);
+                if (dist < r2) {
+                    out->idx.push_back((int64_t)lz * p.g.sz + (int64_t)y * s->nx + x);
+                    out->val.push_back(1.0f - (dist / r2));
+                }
+            }
+    }
+}
+
+template <typename T>
+int scatter_to(fs3d_sim* s, Part& p, const Stamp& st, int field, float scale, int cell_type) {
+    const int n = (int)st.idx.size();
+    if (!n) return FS_OK;
+    int64_t* didx = nullptr; float* dval = nullptr;
+    SIM_HIP(hipMalloc((void**)&didx, n * sizeof(int64_t)));
+    SIM_HIP(hipMalloc((void**)&dval, n * sizeof(float)));
+    SIM_HIP(hipMemcpyAsync(didx, st.idx.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
+    SIM_HIP(hipMemcpyAsync(dval, st.val.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    if (field >= 0)
+        hipLaunchKernelGGL(k_scatter<T>, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, dval, scale, F<T>(p, s->cur, field));
+    if (cell_type >= 0)
+        hipLaunchKernelGGL(k_scatter_cells, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, (uint8_t)cell_type, p.cells);
+    SIM_HIP(hipGetLastError());
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    (void)hipFree(didx); (void)hipFree(dval);
+    return FS_OK;
+}
+
+template <typename T>
+int sphere_emitter(fs3d_sim* s, float radius, float cx, float cy, float cz, float strength) {
+    for (Part& p : s->parts) {
+        Stamp st;
+        sphere_cells(s, p, radius, cx, cy, cz, &st);
+        // main.cpp:53-55: StaticFluid, density = w, v = 20 w
+        FS_TRY(scatter_to<T>(s, p, st, 3, 1.0f, FS_CELL_STATIC_FLUID));
+        FS_TRY(scatter_to<T>(s, p, st, 1, strength, -1));
+    }
+    s->cells_dirty = true;
+    return FS_OK;
+}
+
+template <typename T>
+int fill_sphere(fs3d_sim* s, float radius, float cx, float cy, float cz) {
+    for (Part& p : s->parts) {
+        Stamp st;
+        sphere_cells(s, p, radius, cx, cy, cz, &st);
+        FS_TRY(scatter_to<T>(s, p, st, 3, 1.0f, -1));   // main.cpp:69-71
+    }
+    return FS_OK;
+}
+
+template <typename T>
+__global__ void k_bottom_influence(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w, uint8_t* __restrict__ cells) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+    const int gz = z + g.gz0;
+    if (x < 1 || y < 1 || gz < 1 || x > g.nx - 2 || y > g.ny - 2 || gz > g.gnz - 2) return;
+    const int64_t i = gidx(g, x, y, z);
+    // main.cpp:78-85
+    u[i] = (T)((1.0f - ((float)x / (float)g.nx)) * 1.0f);
+    v[i] = (T)((1.0f - ((float)y / (float)g.ny)) * 1.0f);
+    w[i] = (T)((1.0f - ((float)gz / (float)g.gnz)) * 1.0f);
+    if (x == 1 || y == 1 || gz == 1) cells[i] = FS_CELL_STATIC_FLUID;
+}
+
+template <typename T>
+__global__ void k_clear_interior(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w, T* __restrict__ d) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+    const int gz = z + g.gz0;
+    if (x < 1 || y < 1 || gz < 1 || x > g.nx - 2 || y > g.ny - 2 || gz > g.gnz - 2) return;
+    const int64_t i = gidx(g, x, y, z);
+    u[i] = 0; v[i] = 0; w[i] = 0; d[i] = 0;   // main.cpp:91-94
+}
+
+template <typename T>
+__global__ void k_source_box(Grid g, T* __restrict__ d, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + x0, y = blockIdx.y * blockDim.y + threadIdx.y + y0;
+    const int gz = blockIdx.z + z0, lz = gz - g.gz0;
+    if (x >= x1 || y >= y1 || gz >= z1 || lz < 0 || lz >= g.nzl) return;
+    d[gidx(g, x, y, lz)] = (T)1;   // include/Grid2.h:58
+}
+
+template <typename T>
+int scene_kernel(fs3d_sim* s, int what, const int* box) {
+    for (Part& p : s->parts) {
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
+        if (what == 0)
+            hipLaunchKernelGGL(k_bottom_influence<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), p.cells);
+        else if (what == 1)
+            hipLaunchKernelGGL(k_clear_interior<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), F<T>(p, s->cur, 3));
+        else {
+            const int ex = box[1] - box[0], ey = box[3] - box[2], ez = box[5] - box[4];
+            if (ex <= 0 || ey <= 0 || ez <= 0) continue;
+            dim3 gb(div_up(ex, 64), div_up(ey, 4), ez);
+            hipLaunchKernelGGL(k_source_box<T>, gb, b, 0, s->stream, p.g, F<T>(p, s->cur, 3), box[0], box[1], box[2], box[3], box[4], box[5]);
+        }
+    }
+    SIM_HIP(hipGetLastError());
+    if (what == 0) s->cells_dirty = true;
+    return FS_OK;
+}
+
+bool config_ok(const fs3d_config* c, std::string* why) {
+    if (c->dtype != FS_F32 && c->dtype != FS_F64) { *why = "dtype must be FS_F32 or FS_F64"; return false; }
+    if (c->ordering != FS_ORDER_RED_BLACK && c->ordering != FS_ORDER_LEXICOGRAPHIC) { *why = "bad ordering"; return false; }
+    if (c->stop_mode < FS_STOP_FIXED || c->stop_mode > FS_STOP_L2_RESIDUAL) { *why = "bad stop_mode"; return false; }
+    if (c->step_mode != FS_STEP_REFERENCE && c->step_mode != FS_STEP_REFLECTION) { *why = "bad step_mode"; return false; }
+    if (c->max_iters < 1) { *why = "max_iters must be >= 1"; return false; }
+    if (c->check_every < 1) { *why = "check_every must be >= 1"; return false; }
+    if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
+    if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
+    return true;
+}
+
+int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, int nranks, const uint8_t* id,
+                  fs3d_sim** out) {
+    if (!out) return FS_EINVAL;
+    *out = nullptr;
+    fs3d_config cfg;
+    if (cfg_in) cfg = *cfg_in; else fs3d_default_config(&cfg);
+    std::string why;
+    if (nx < 3 || ny < 3 || nz < 3 || !config_ok(&cfg, &why) || rank < 0 || rank >= nranks) return FS_EINVAL;
+    if (cfg.ordering == FS_ORDER_LEXICOGRAPHIC && (nranks > 1 || cfg.local_slabs > 1)) return FS_EINVAL;
+    fs3d_sim* s = new (std::nothrow) fs3d_sim();
+    if (!s) return FS_ENOMEM;
+    *out = s;   // handed back even on failure so that the caller can read the error text, then destroy
+    s->cfg = cfg;
+    s->nx = nx; s->ny = ny; s->nz = nz;
+    s->esz = cfg.dtype == FS_F64 ? 8 : 4;
+    s->rank = rank; s->nranks = nranks; s->nlocal = cfg.local_slabs; s->nparts_global = nranks * cfg.local_slabs;
+    if (cfg.device >= 0) s->device = cfg.device;
+    else SIM_HIP(hipGetDevice(&s->device));
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return set_err(s, FS_EHIP, "hipSetDevice failed");
+    SIM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto& e : s->ev) SIM_HIP(hipEventCreate(&e));
+    SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 2)));
+    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 2, hipHostMallocDefault));
+    SIM_HIP(hipMalloc((void**)&s->doob, sizeof(int)));
+    SIM_HIP(hipHostMalloc((void**)&s->hoob, sizeof(int), hipHostMallocDefault));
+    if (nranks > 1) {
+        s->rccl = Rccl::get(s->err);
+        if (!s->rccl) return FS_ECOMM;
+        ncclUniqueId uid;
+        static_assert(sizeof(uid) == FS_COMM_ID_BYTES, "unique id size");
+        memcpy(&uid, id, sizeof uid);
+        FS_TRY(nccl_check(s, s->rccl->CommInitRank(&s->comm, nranks, uid, rank), "ncclCommInitRank"));
+    }
+    FS_TRY(alloc_parts(s));
+    FS_TRY(zero_fields(s));
+    FS_TRY(init_cells(s));
+    for (int k = 0; k < 3; ++k) SIM_HIP(hipEventRecord(s->ev[k], s->stream));
+    SIM_HIP(hipEventRecord(s->ev[3], s->stream));
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char* fsamd_version(void) { return "fluidsim_amd 0.1 (gfx950)"; }
+
+void fs3d_default_config(fs3d_config* c) {
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->device = -1;
+    c->dtype = FS_F32;
+    c->ordering = FS_ORDER_RED_BLACK;
+    c->stop_mode = FS_STOP_L1_CHANGE;   // main.cpp:108
+    c->max_iters = 1000;
+    c->check_every = 1;
+    c->step_mode = FS_STEP_REFERENCE;
+    c->local_slabs = 1;
+    c->tol = 5.0;
+    c->omega = 1.0;
+    c->buoyancy = 0.0;
+}
+
+int fs3d_create(int nx, int ny, int nz, const fs3d_config* cfg, fs3d_sim** out) {
+    return create_common(nx, ny, nz, cfg, 0, 1, nullptr, out);
+}
+
+int fsamd_comm_unique_id(uint8_t id[FS_COMM_ID_BYTES]) {
+    std::string err;
+    Rccl* R = Rccl::get(err);
+    if (!R || !id) return FS_ECOMM;
+    ncclUniqueId uid;
+    if (R->GetUniqueId(&uid) != ncclSuccess) return FS_ECOMM;
+    memcpy(id, &uid, sizeof uid);
+    return FS_OK;
+}
+
+int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config* cfg, int rank, int nranks,
+                     const uint8_t id[FS_COMM_ID_BYTES], fs3d_sim** out) {
+    if (nranks < 1 || (nranks > 1 && !id)) return FS_EINVAL;
+    return create_common(nx, ny, nz_global, cfg, rank, nranks, id, out);
+}
+
+int fs3d_slab_range(const fs3d_sim* s, int* z0, int* z1, int* halo) {
+    if (!s || s->parts.empty()) return FS_EINVAL;
+    int a, b;
+    owned_range(s, &a, &b);
+    if (z0) *z0 = a;
+    if (z1) *z1 = b;
+    if (halo) *halo = s->parts.front().H;
+    return FS_OK;
+}
+
+void fs3d_destroy(fs3d_sim* s) {
+    if (!s) return;
+    DeviceGuard guard(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
+    free_parts(s);
+    (void)hipFree(s->dres); (void)hipFree(s->doob);
+    if (s->hres) (void)hipHostFree(s->hres);
+    if (s->hoob) (void)hipHostFree(s->hoob);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int fs3d_reset(fs3d_sim* s) {
+    SIM_GUARD(s);
+    FS_TRY(zero_fields(s));
+    FS_TRY(init_cells(s));
+    s->cur = 0;
+    s->stats = fs3d_stats{};
+    s->halo_dirty = true;
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+int fs3d_set_config(fs3d_sim* s, const fs3d_config* c) {
+    if (!s || !c) return FS_EINVAL;
+    std::string why;
+    if (!config_ok(c, &why)) return set_err(s, FS_EINVAL, why);
+    if (c->dtype != s->cfg.dtype || c->local_slabs != s->cfg.local_slabs)
+        return set_err(s, FS_EINVAL, "dtype and local_slabs are fixed at creation");
+    if (c->ordering == FS_ORDER_LEXICOGRAPHIC && s->nparts_global > 1)
+        return set_err(s, FS_EINVAL, "lexicographic order needs a single slab");
+    const int dev = s->cfg.device;
+    s->cfg = *c;
+    s->cfg.device = dev;
+    return FS_OK;
+}
+
+int fs3d_get_config(const fs3d_sim* s, fs3d_config* c) {
+    if (!s || !c) return FS_EINVAL;
+    *c = s->cfg;
+    c->device = s->device;
+    return FS_OK;
+}
+
+const char* fs3d_last_error(const fs3d_sim* s) { return s ? s->err.c_str() : "null handle"; }
+
+int fs3d_set_field(fs3d_sim* s, int which, const void* host, size_t count) {
+    SIM_GUARD(s);
+    if (!host || which < FS_FIELD_U || which > FS_FIELD_DENSITY) return set_err(s, FS_EINVAL, "bad field or null pointer");
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny;
+    if (count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    for (Part& p : s->parts) {
+        char* dst = (char*)field_ptr(s, p, which) + (size_t)p.H * plane * s->esz;
+        const char* src = (const char*)host + (size_t)(p.z0 - z0) * plane * s->esz;
+        SIM_HIP(hipMemcpy(dst, src, (size_t)p.own_planes() * plane * s->esz, hipMemcpyHostToDevice));
+    }
+    s->halo_dirty = true;
+    return FS_OK;
+}
+
+int fs3d_get_field(fs3d_sim* s, int which, void* host, size_t count) {
+    SIM_GUARD(s);
+    if (!host || which < FS_FIELD_U || which > FS_FIELD_DIVERGENCE) return set_err(s, FS_EINVAL, "bad field or null pointer");
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny;
+    if (count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
+    if (which == FS_FIELD_DIVERGENCE) {
+        FS_TRY(prepare(s));
+        for (Part& p : s->parts) SIM_HIP(hipMemsetAsync(p.tmp[0], 0, p.n * s->esz, s->stream));
+        FS_TRY(DISPATCH(s, residual, s, nullptr, nullptr, true));
+    }
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    for (Part& p : s->parts) {
+        const char* src = (const char*)field_ptr(s, p, which) + (size_t)p.H * plane * s->esz;
+        char* dst = (char*)host + (size_t)(p.z0 - z0) * plane * s->esz;
+        SIM_HIP(hipMemcpy(dst, src, (size_t)p.own_planes() * plane * s->esz, hipMemcpyDeviceToHost));
+    }
+    return FS_OK;
+}
+
+int fs3d_get_field_plane(fs3d_sim* s, int which, int z, void* host, size_t count) {
+    SIM_GUARD(s);
+    if (!host || which < FS_FIELD_U || which > FS_FIELD_DENSITY) return set_err(s, FS_EINVAL, "bad field or null pointer");
+    const size_t plane = (size_t)s->nx * s->ny;
+    if (count != plane) return set_err(s, FS_EINVAL, "count must be nx*ny");
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    for (Part& p : s->parts)
+        if (z >= p.z0 && z < p.z1) {
+            const char* src = (const char*)field_ptr(s, p, which) + (size_t)(z - p.g.gz0) * plane * s->esz;
+            SIM_HIP(hipMemcpy(host, src, plane * s->esz, hipMemcpyDeviceToHost));
+            return FS_OK;
+        }
+    return set_err(s, FS_EINVAL, "plane not owned by this handle");
+}
+
+int fs3d_set_cell_types(fs3d_sim* s, const uint8_t* host, size_t count) {
+    SIM_GUARD(s);
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny;
+    if (!host || count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    for (Part& p : s->parts) {
+        std::vector<uint8_t> h((size_t)p.own_planes() * plane);
+        for (int z = p.z0; z < p.z1; ++z)
+            for (int y = 0; y < s->ny; ++y)
+                for (int x = 0; x < s->nx; ++x) {
+                    const bool shell = z == 0 || z == s->nz - 1 || y == 0 || y == s->ny - 1 || x == 0 || x == s->nx - 1;
+                    uint8_t t = host[(size_t)(z - z0) * plane + (size_t)y * s->nx + x];
+                    if (t > FS_CELL_STATIC_FLUID) return set_err(s, FS_EINVAL, "cell type out of range");
+                    h[(size_t)(z - p.z0) * plane + (size_t)y * s->nx + x] = shell ? (uint8_t)FS_CELL_OBJECT : t;
+                }
+        SIM_HIP(hipMemcpy(p.cells + (size_t)p.H * plane, h.data(), h.size(), hipMemcpyHostToDevice));
+    }
+    s->cells_dirty = true;
+    return FS_OK;
+}
+
+int fs3d_get_cell_types(fs3d_sim* s, uint8_t* host, size_t count) {
+    SIM_GUARD(s);
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny;
+    if (!host || count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    for (Part& p : s->parts)
+        SIM_HIP(hipMemcpy(host + (size_t)(p.z0 - z0) * plane, p.cells + (size_t)p.H * plane, (size_t)p.own_planes() * plane,
+                          hipMemcpyDeviceToHost));
+    return FS_OK;
+}
+
+int fs3d_sphere_emitter(fs3d_sim* s, float radius, float cx, float cy, float cz, float strength) {
+    SIM_GUARD(s);
+    if (!(radius > 0)) return set_err(s, FS_EINVAL, "radius must be positive");
+    s->halo_dirty = true;
+    return DISPATCH(s, sphere_emitter, s, radius, cx, cy, cz, strength);
+}
+
+int fs3d_sphere_influence(fs3d_sim* s, float radius) {
+    if (!s) return FS_EINVAL;
+    return fs3d_sphere_emitter(s, radius, s->nx / 2.0f, radius, s->nz / 2.0f, 20.0f);   // main.cpp:46-55
+}
+
+int fs3d_fill_sphere(fs3d_sim* s, float radius, float cx, float cy, float cz, int iter) {
+    SIM_GUARD(s);
+    if (iter % 100 != 0) return FS_OK;   // main.cpp:69
+    s->halo_dirty = true;
+    return DISPATCH(s, fill_sphere, s, radius, cx, cy, cz);
+}
+
+int fs3d_fill_sphere_influence(fs3d_sim* s, float radius, int iter) {
+    if (!s) return FS_EINVAL;
+    return fs3d_fill_sphere(s, radius, s->nx / 2.0f, radius, s->nz / 2.0f, iter);
+}
+
+int fs3d_bottom_influence(fs3d_sim* s) {
+    SIM_GUARD(s);
+    s->halo_dirty = true;
+    return DISPATCH(s, scene_kernel, s, 0, nullptr);
+}
+
+int fs3d_clear(fs3d_sim* s) {
+    SIM_GUARD(s);
+    s->halo_dirty = true;
+    return DISPATCH(s, scene_kernel, s, 1, nullptr);
+}
+
+int fs3d_apply_source(fs3d_sim* s, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax) {
+    SIM_GUARD(s);
+    // include/Grid2.h:56-57: integer truncation of fraction * resolution, half-open ranges
+    int box[6] = {(int)(xmin * s->nx), (int)(xmax * s->nx), (int)(ymin * s->ny), (int)(ymax * s->ny),
+                  (int)(zmin * s->nz), (int)(zmax * s->nz)};
+    if (box[0] < 0 || box[2] < 0 || box[4] < 0 || box[1] > s->nx || box[3] > s->ny || box[5] > s->nz)
+        return set_err(s, FS_EINVAL, "source box outside the grid");
+    s->halo_dirty = true;
+    return DISPATCH(s, scene_kernel, s, 2, box);
+}
+
+int fs3d_gauss_seidel_projection(fs3d_sim* s, double* change) {
+    SIM_GUARD(s);
+    FS_TRY(prepare(s));
+    double c = 0;
+    FS_TRY(DISPATCH(s, sweep_with_change, s, &c));
+    s->halo_dirty = s->nparts_global > 1;
+    if (change) *change = c;
+    return FS_OK;
+}
+
+int fs3d_sweeps(fs3d_sim* s, int n) {
+    SIM_GUARD(s);
+    FS_TRY(prepare(s));
+    for (int i = 0; i < n; ++i) FS_TRY(DISPATCH(s, sweep_once, s));
+    s->halo_dirty = s->nparts_global > 1;
+    return FS_OK;
+}
+
+int fs3d_time_sweeps(fs3d_sim* s, int n, double* ms) {
+    SIM_GUARD(s);
+    FS_TRY(prepare(s));
+    SIM_HIP(hipEventRecord(s->ev[0], s->stream));
+    for (int i = 0; i < n; ++i) FS_TRY(DISPATCH(s, sweep_once, s));
+    SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+    SIM_HIP(hipEventSynchronize(s->ev[1]));
+    float t = 0;
+    SIM_HIP(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+    s->halo_dirty = s->nparts_global > 1;
+    if (ms) *ms = t;
+    return FS_OK;
+}
+
+int fs3d_project(fs3d_sim* s, int* sweeps, double* metric) {
+    SIM_GUARD(s);
+    s->resid_dt = 1.0;
+    return DISPATCH(s, project, s, sweeps, metric);
+}
+
+int fs3d_residual(fs3d_sim* s, double* l2, double* max_abs_div) {
+    SIM_GUARD(s);
+    FS_TRY(prepare(s));
+    return DISPATCH(s, residual, s, l2, max_abs_div, false);
+}
+
+int fs3d_semi_lagrange(fs3d_sim* s, double t_step) {
+    SIM_GUARD(s);
+    return DISPATCH(s, advect, s, t_step, false, 1);
+}
+
+int fs3d_update(fs3d_sim* s, double t_step) {
+    SIM_GUARD(s);
+    s->stats.sweeps_step = 0;
+    s->resid_dt = t_step > 0 ? t_step : 1.0;
+    FS_TRY(DISPATCH(s, project, s, nullptr, nullptr));
+    return DISPATCH(s, advect, s, t_step, false, 1);
+}
+
+int fs3d_advance(fs3d_sim* s, double dt) {
+    SIM_GUARD(s);
+    return DISPATCH(s, step, s, dt);
+}
+
+int fs3d_get_stats(fs3d_sim* s, fs3d_stats* out) {
+    SIM_GUARD(s);
+    if (!out) return FS_EINVAL;
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    float a = 0, b = 0, c = 0;
+    if (s->stats.step > 0) {
+        (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
+        (void)hipEventElapsedTime(&b, s->ev[1], s->ev[2]);
+        (void)hipEventElapsedTime(&c, s->ev[0], s->ev[3]);
+    }
+    s->stats.ms_project = a; s->stats.ms_advect = b; s->stats.ms_step = c;
+    *out = s->stats;
+    return FS_OK;
+}
+
+int fs3d_synchronize(fs3d_sim* s) {
+    SIM_GUARD(s);
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// Device kernels of the 3D MAC-grid fluid step for gfx950 (wave64).
+//
+// Layout: every field is a dense array of nx*ny*nzl scalars, x fastest
+// (i = (z*ny + y)*nx + x, the reference's index(), advection-reflection/
+// main.cpp:319-325).  nzl counts the planes held by this slab, halo planes
+// included; gz0 is the global z coordinate of local plane 0 (0 on a single
+// GPU).  u[i], v[i], w[i] live on the low-x/low-y/low-z face of cell i.
+//
+// All kernels are HBM-bandwidth bound: x runs along the 64 lanes of a wave so
+// that every wave-instruction touches whole 256-byte segments.
+//
+// Bit parity with the CPU restatement needs IEEE division and no fused
+// multiply-add: build with -ffp-contract=off and without fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsamd {
+
+// Per-cell flag byte derived from the cell types (main.cpp:209-215, :227-232):
+// bits 0..5 = the x-,x+,y-,y+,z-,z+ neighbour is Fluid; bit 6 = the cell is
+// Fluid; bit 7 = the cell is Object.  popcount(bits 0..5) is the reference's s.
+enum : uint32_t {
+    FL_XM = 1u, FL_XP = 2u, FL_YM = 4u, FL_YP = 8u, FL_ZM = 16u, FL_ZP = 32u,
+    FL_NBR = 63u, FL_SELF_FLUID = 64u, FL_SELF_OBJECT = 128u
+};
+
+struct Grid {
+    int nx, ny, nzl;   // local extents (nzl includes halo planes)
+    int gz0;           // global z of local plane 0
+    int gnz;           // global number of planes
+    int64_t sy, sz;    // strides: sy = nx, sz = nx*ny
+};
+
+__device__ __forceinline__ int64_t gidx(const Grid& g, int x, int y, int z) {
+    return (int64_t)z * g.sz + (int64_t)y * g.sy + x;
+}
+
+// ---------------------------------------------------------------------------
+// cell types -> flags.  Planes outside the global domain and neighbours outside
+// the local array count as Object.
+__global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t* __restrict__ flags) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    const int64_t i = gidx(g, x, y, z);
+    auto type_at = [&](int xx, int yy, int zz) -> uint32_t {
+        if (xx < 0 || yy < 0 || zz < 0 || xx >= g.nx || yy >= g.ny || zz >= g.nzl) return 1u;
+        return cells[gidx(g, xx, yy, zz)];
+    };
+    const uint32_t self = cells[i];
+    uint32_t f = 0;
+    if (type_at(x - 1, y, z) == 0u) f |= FL_XM;
+    if (type_at(x + 1, y, z) == 0u) f |= FL_XP;
+    if (type_at(x, y - 1, z) == 0u) f |= FL_YM;
+    if (type_at(x, y + 1, z) == 0u) f |= FL_YP;
+    if (type_at(x, y, z - 1) == 0u) f |= FL_ZM;
+    if (type_at(x, y, z + 1) == 0u) f |= FL_ZP;
+    if (self == 0u) f |= FL_SELF_FLUID;
+    if (self == 1u) f |= FL_SELF_OBJECT;
+    flags[i] = (uint8_t)f;
+}
+
+// ---------------------------------------------------------------------------
+// Projection, red-black order.
+//
+// The reference visits a cell, computes dd = div/s and pushes +dd onto the
+// cell's low faces and -dd onto its high faces under the mask predicates of
+// main.cpp:227-232.  Every face touches exactly one cell of each colour, so
+// within one colour the six faces of a cell are read and written by that
+// cell's visit alone: one colour is one race-free in-place parallel pass, and
+// its result does not depend on the visiting order inside the colour.
+template <typename T>
+__device__ __forceinline__ T cell_dd(const Grid& g, const T* __restrict__ u, const T* __restrict__ v,
+                                     const T* __restrict__ w, int64_t c, uint32_t fl, T omega) {
+    // main.cpp:217-225
+    const T div = (u[c + 1] - u[c]) + (v[c + g.sy] - v[c]) + (w[c + g.sz] - w[c]);
+    T dd = div / (T)__popc(fl & FL_NBR);
+    if (omega != (T)1) dd = omega * dd;
+    return dd;
+}
+
+__device__ __forceinline__ bool relaxes(uint32_t fl) {   // main.cpp:199, :221
+    return !(fl & FL_SELF_OBJECT) && (fl & FL_NBR);
+}
+
+// One thread per cell of the active colour: x = 1 + 2*t + (row offset), y in
+// [1,ny-2], z in [zb, ze).  A slab's top cells write their high-z face into the
+// slab's ghost copy of the interface plane.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_rb_halfsweep(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w,
+               const uint8_t* __restrict__ flags, int colour, T omega, int zb, int ze) {
+    const int y = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    const int z = blockIdx.z + zb;
+    if (y > g.ny - 2) return;
+    // first interior x of the active colour in this row: (x + y + z + gz0) & 1 == colour
+    const int x = 1 + 2 * (blockIdx.x * blockDim.x + threadIdx.x) + ((1 + y + z + g.gz0 + colour) & 1);
+    if (x > g.nx - 2) return;
+    const int64_t i = gidx(g, x, y, z);
+    const uint32_t fl = flags[i];
+    if (!relaxes(fl)) return;
+    const T dd = cell_dd(g, u, v, w, i, fl, omega);
+    const bool self = fl & FL_SELF_FLUID;
+    if ((fl & FL_XM) && self) u[i] += dd;      // main.cpp:227-232
+    if (fl & FL_XP) u[i + 1] -= dd;
+    if ((fl & FL_YM) && self) v[i] += dd;
+    if (fl & FL_YP) v[i + g.sy] -= dd;
+    if ((fl & FL_ZM) && self) w[i] += dd;
+    if (fl & FL_ZP) w[i + g.sz] -= dd;
+}
+
+// After a half-sweep the two slabs either side of an interface each hold the
+// fresh value of w on a complementary checkerboard half of the interface
+// plane.  take_parity selects the half that the other slab updated.
+template <typename T>
+__global__ void k_merge_w_plane(Grid g, T* __restrict__ w, const T* __restrict__ recv, int z, int take_parity) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.nx || y >= g.ny) return;
+    if (((x + y + z + g.gz0) & 1) == take_parity) w[gidx(g, x, y, z)] = recv[(int64_t)y * g.nx + x];
+}
+
+// ---------------------------------------------------------------------------
+// Projection, the reference's lexicographic order (main.cpp:235) executed as
+// hyperplane wavefronts: all cells with x+y+z == k are independent of each
+// other, their low neighbours lie on plane k-1 and their high neighbours on
+// k+1, so running k upwards reproduces the serial sweep bit for bit.
+template <typename T>
+__global__ void k_lexi_hyperplane(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w,
+                                  const uint8_t* __restrict__ flags, int k, T omega) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int z = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (y > g.ny - 2 || z > g.nzl - 2) return;
+    const int x = k - y - z;
+    if (x < 1 || x > g.nx - 2) return;
+    const int64_t i = gidx(g, x, y, z);
+    const uint32_t fl = flags[i];
+    if (!relaxes(fl)) return;
+    const T dd = cell_dd(g, u, v, w, i, fl, omega);
+    const bool self = fl & FL_SELF_FLUID;
+    if ((fl & FL_XM) && self) u[i] += dd;
+    if (fl & FL_XP) u[i + 1] -= dd;
+    if ((fl & FL_YM) && self) v[i] += dd;
+    if (fl & FL_YP) v[i + g.sy] -= dd;
+    if ((fl & FL_ZM) && self) w[i] += dd;
+    if (fl & FL_ZP) w[i + g.sz] -= dd;
+}
+
+// The reference sums the change in one scalar of the working precision, in
+// ascending cell order (main.cpp:243-249).  One wave reproduces that order:
+// the lanes fetch 64 consecutive cells, lane order is cell order, and the
+// running sum is carried through the lanes serially.
+template <typename T>
+__global__ void k_change_serial(Grid g, const T* __restrict__ au, const T* __restrict__ av,
+                                const T* __restrict__ aw, const T* __restrict__ bu, const T* __restrict__ bv,
+                                const T* __restrict__ bw, double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int64_t n = (int64_t)g.nx * g.ny * g.nzl;
+    T acc = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        T a = 0, b = 0, c = 0;
+        if (i < n) {
+            const int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.sz);
+            if (x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && z > 0 && z < g.nzl - 1) {
+                a = fabs(au[i] - bu[i]); b = fabs(av[i] - bv[i]); c = fabs(aw[i] - bw[i]);
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            acc += __shfl(a, l, 64); acc += __shfl(b, l, 64); acc += __shfl(c, l, 64);
+        }
+    }
+    if (lane == 0) out[0] = (double)acc;
+}
+
+// ---------------------------------------------------------------------------
+// Reductions: per-wave shuffle tree, per-block LDS, one partial per block; a
+// second one-block kernel adds the partials in a fixed order so that results
+// are reproducible from run to run.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// blockDim.x must be 256.  Returns the block total in thread 0.
+__device__ __forceinline__ void block_sum_max(double& s, double& m) {
+    __shared__ double ls[4], lm[4];
+    s = wave_sum(s); m = wave_max(m);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { ls[wid] = s; lm[wid] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ls[0] + ls[1] + ls[2] + ls[3];
+        m = fmax(fmax(lm[0], lm[1]), fmax(lm[2], lm[3]));
+    }
+}
+
+// L1 norm of (a - b) over the interior locations of planes [zb, ze).
+// part[2*block] = sum, part[2*block+1] = unused max slot.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_change_l1(Grid g, const T* __restrict__ au, const T* __restrict__ av, const T* __restrict__ aw,
+            const T* __restrict__ bu, const T* __restrict__ bv, const T* __restrict__ bw, int zb, int ze,
+            double* __restrict__ part) {
+    const int64_t rows = (int64_t)(g.ny - 2) * (ze - zb);
+    double s = 0, m = 0;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int y = (int)(r % (g.ny - 2)) + 1, z = (int)(r / (g.ny - 2)) + zb;
+        const int64_t row = gidx(g, 0, y, z);
+        for (int x = threadIdx.x + 1; x < g.nx - 1; x += 256) {
+            const int64_t i = row + x;
+            s += (double)fabs(au[i] - bu[i]);
+            s += (double)fabs(av[i] - bv[i]);
+            s += (double)fabs(aw[i] - bw[i]);
+        }
+    }
+    block_sum_max(s, m);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0; }
+}
+
+// Sum of squared divergences and max |div| over the cells a visit can relax
+// (not Object, s > 0, and at least one face the visit may move: a StaticFluid
+// cell moves only its high faces, main.cpp:227-232), planes [zb, ze).
+// Optionally stores the divergence field.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_div_sumsq(Grid g, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ w,
+            const uint8_t* __restrict__ flags, int zb, int ze, double* __restrict__ part, T* __restrict__ div_out) {
+    const int64_t rows = (int64_t)(g.ny - 2) * (ze - zb);
+    double s = 0, m = 0;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int y = (int)(r % (g.ny - 2)) + 1, z = (int)(r / (g.ny - 2)) + zb;
+        const int64_t row = gidx(g, 0, y, z);
+        for (int x = threadIdx.x + 1; x < g.nx - 1; x += 256) {
+            const int64_t i = row + x;
+            const uint32_t fl = flags[i];
+            const T div = (u[i + 1] - u[i]) + (v[i + g.sy] - v[i]) + (w[i + g.sz] - w[i]);
+            if (div_out) div_out[i] = div;
+            const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
+            if (relaxes(fl) && movable) {
+                const double dv = (double)div;
+                s += dv * dv;
+                m = fmax(m, fabs(dv));
+            }
+        }
+    }
+    block_sum_max(s, m);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = m; }
+}
+
+// out[0] = sum of part[2b], out[1] = max of part[2b+1], b ascending.
+__global__ void __launch_bounds__(256) k_reduce_final(const double* __restrict__ part, int nblocks,
+                                                      double* __restrict__ out) {
+    double s = 0, m = 0;
+    // fixed order: thread t adds blocks t, t+256, ...; then the fixed tree of block_sum_max
+    for (int b = threadIdx.x; b < nblocks; b += 256) { s += part[2 * b]; m = fmax(m, part[2 * b + 1]); }
+    block_sum_max(s, m);
+    if (threadIdx.x == 0) { out[0] = s; out[1] = m; }
+}
+
+// ---------------------------------------------------------------------------
+// Semi-Lagrangian advection (main.cpp:256-291, sampler :380-435).
+//
+// safeSample: zero outside the grid, zero on the boundary shell, zero for
+// non-finite values (main.cpp:411-435).  Coordinates are global; a sample
+// whose plane is not held by this slab raises *oob instead.
+template <typename T>
+__device__ __forceinline__ T safe_sample(const Grid& g, const T* __restrict__ q, int x, int y, int z,
+                                         int* __restrict__ oob) {
+    if (x < 1 || y < 1 || z < 1 || x >= g.nx - 1 || y >= g.ny - 1 || z >= g.gnz - 1) return (T)0;
+    const int lz = z - g.gz0;
+    if (lz < 0 || lz >= g.nzl) { *oob = 1; return (T)0; }
+    const T val = q[gidx(g, x, y, lz)];
+    return isfinite(val) ? val : (T)0;
+}
+
+// sample() of main.cpp:380-409: same backtrace, same weight grouping, same
+// order of the eight terms.
+template <typename T>
+__device__ __forceinline__ T trace_sample(const Grid& g, const T* __restrict__ q, int x, int y, int gz, T dx,
+                                          T dy, T dz, T t_step, int* __restrict__ oob) {
+    const T px = (T)x - dx * t_step;
+    const T py = (T)y - dy * t_step;
+    const T pz = (T)gz - dz * t_step;
+    const T bx = floor(px), tx = bx + (T)1, fu = (px - bx) / (tx - bx);
+    const T by = floor(py), ty = by + (T)1, fv = (py - by) / (ty - by);
+    const T bz = floor(pz), tz = bz + (T)1, fw = (pz - bz) / (tz - bz);
+    const int ibx = (int)bx, itx = (int)tx, iby = (int)by, ity = (int)ty, ibz = (int)bz, itz = (int)tz;
+    const T one = (T)1;
+    T r = 0;
+    r += safe_sample(g, q, ibx, iby, ibz, oob) * ((one - fu) * (one - fv) * (one - fw));
+    r += safe_sample(g, q, itx, iby, ibz, oob) * ((fu) * (one - fv) * (one - fw));
+    r += safe_sample(g, q, ibx, ity, ibz, oob) * ((one - fu) * (fv) * (one - fw));
+    r += safe_sample(g, q, ibx, iby, itz, oob) * ((one - fu) * (one - fv) * (fw));
+    r += safe_sample(g, q, itx, ity, ibz, oob) * ((fu) * (fv) * (one - fw));
+    r += safe_sample(g, q, itx, iby, itz, oob) * ((fu) * (one - fv) * (fw));
+    r += safe_sample(g, q, ibx, ity, itz, oob) * ((one - fu) * (fv) * (fw));
+    r += safe_sample(g, q, itx, ity, itz, oob) * ((fu) * (fv) * (fw));
+    return r;
+}
+
+// One thread per location of planes [zb, ze): carries (qu,qv,qw,qd) along the
+// velocity (U,V,W) into (ou,ov,ow,od).  Locations the reference does not
+// advect (non-Fluid faces, Object densities, the shell) copy q.  density_mode 1
+// is the reference's cell-centre velocity: the cell's own, already advected
+// low faces averaged with the not yet advected high faces (main.cpp:285-287 in
+// serial order); density_mode 0 averages the carrying velocity's faces.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
+         const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
+         T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od,
+         const uint8_t* __restrict__ flags, T t_step, int density_mode, int zb, int ze, int* __restrict__ oob_flag) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z + zb;
+    if (x >= g.nx || y >= g.ny) return;
+    const int64_t i = gidx(g, x, y, z);
+    const int gz = z + g.gz0;
+    T nu = qu[i], nv = qv[i], nw = qw[i], nd = qd[i];
+    const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
+    if (interior) {
+        const uint32_t fl = flags[i];
+        int oob = 0;
+        const T four = (T)4, two = (T)2;
+        if (fl & FL_SELF_FLUID) {
+            T dx, dy, dz;
+            // main.cpp:261-266
+            dx = U[i];
+            dy = (V[i] + V[i - 1] + V[i + g.sy] + V[i - 1 + g.sy]) / four;
+            dz = (W[i] + W[i - 1] + W[i + g.sz] + W[i - 1 + g.sz]) / four;
+            nu = trace_sample(g, qu, x, y, gz, dx, dy, dz, t_step, &oob);
+            // main.cpp:269-274
+            dx = (U[i] + U[i - g.sy] + U[i + 1] + U[i + 1 - g.sy]) / four;
+            dy = V[i];
+            dz = (W[i] + W[i - g.sy] + W[i + g.sz] + W[i - g.sy + g.sz]) / four;
+            nv = trace_sample(g, qv, x, y, gz, dx, dy, dz, t_step, &oob);
+            // main.cpp:276-281
+            dx = (U[i] + U[i - g.sz] + U[i + 1] + U[i + 1 - g.sz]) / four;
+            dy = (V[i] + V[i - g.sz] + V[i + g.sy] + V[i + g.sy - g.sz]) / four;
+            dz = W[i];
+            nw = trace_sample(g, qw, x, y, gz, dx, dy, dz, t_step, &oob);
+        }
+        if (!(fl & FL_SELF_OBJECT)) {   // main.cpp:284-289
+            T uc, vc, wc;
+            if (density_mode == 1) {
+                uc = (nu + U[i + 1]) / two; vc = (nv + V[i + g.sy]) / two; wc = (nw + W[i + g.sz]) / two;
+            } else {
+                uc = (U[i] + U[i + 1]) / two; vc = (V[i] + V[i + g.sy]) / two; wc = (W[i] + W[i + g.sz]) / two;
+            }
+            nd = trace_sample(g, qd, x, y, gz, uc, vc, wc, t_step, &oob);
+        }
+        if (oob) *oob_flag = 1;
+    }
+    ou[i] = nu; ov[i] = nv; ow[i] = nw; od[i] = nd;
+}
+
+// Reflection about the projected field (Zehnder et al. 2018, Alg. 1):
+// out = 2*proj - tilde for the three velocity components.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reflect(int64_t n, const T* __restrict__ pu, const T* __restrict__ pv, const T* __restrict__ pw,
+          const T* __restrict__ tu, const T* __restrict__ tv, const T* __restrict__ tw, T* __restrict__ ou,
+          T* __restrict__ ov, T* __restrict__ ow) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        ou[i] = (T)2 * pu[i] - tu[i];
+        ov[i] = (T)2 * pv[i] - tv[i];
+        ow[i] = (T)2 * pw[i] - tw[i];
+    }
+}
+
+// Buoyancy on low-y faces between two Fluid cells, the 3D form of
+// 3_fluid/FluidSim.h:109-118 and :136-148: v += dt * (coef*(d[y-1]+d[y])/2*(64/nx)).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_buoyancy(Grid g, T* __restrict__ v, const T* __restrict__ d, const uint8_t* __restrict__ flags, T dt, T coef,
+           int zb, int ze) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    const int z = blockIdx.z + zb;
+    if (x > g.nx - 2 || y > g.ny - 2) return;
+    const int64_t i = gidx(g, x, y, z);
+    const uint32_t fl = flags[i];
+    if (!(fl & FL_SELF_FLUID) || !(fl & FL_YM)) return;
+    const T scaling = (T)64 / (T)g.nx;
+    const T f = coef * (d[i - g.sy] + d[i]) / (T)2 * scaling;
+    v[i] += dt * f;
+}
+
+// Sparse stamps used by the emitters: field[idx[k]] = val[k]; cells[idx[k]] = type.
+template <typename T>
+__global__ void k_scatter(int n, const int64_t* __restrict__ idx, const float* __restrict__ val, float scale,
+                          T* __restrict__ field) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) field[idx[k]] = (T)(scale * val[k]);
+}
+__global__ void k_scatter_cells(int n, const int64_t* __restrict__ idx, uint8_t type, uint8_t* __restrict__ cells) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) cells[idx[k]] = type;
+}
+
+}  // namespace fsamd

@@ -1,0 +1,191 @@
+/*
+ * fluidsim_amd.h -- C ABI of the MI355X (gfx950) fluid step.
+ *
+ * The reference has no FFI boundary: its 3D solver is the C++ class FluidSim
+ * in advection-reflection/main.cpp:21-442 and its 2D solver the class FluidSim
+ * in 3_fluid/FluidSim.h:11-303 behind the abstract Simulation interface
+ * (include/Simulation.h:11-78).  Each entry point below names the reference
+ * member function it replaces.  The C++ adapters that give those classes'
+ * method names back to a C++ caller live in include/fsamd/.
+ *
+ * Conventions
+ *  - every function returns FS_OK (0) or a negative FS_E* code; the text of the
+ *    last failure on a handle is returned by fs3d_last_error();
+ *  - fields are dense arrays of nx*ny*nz scalars, x fastest:
+ *    i = (z*ny + y)*nx + x (main.cpp:319-325).  u[i], v[i], w[i] are the
+ *    velocities on the low-x / low-y / low-z face of cell i, in cells per
+ *    second (main.cpp:137-139, :217-219);
+ *  - host pointers only; the library owns all device memory and its stream;
+ *  - a handle may be used from different host threads over its life, but
+ *    calls on one handle must not overlap (the discipline of the reference's
+ *    Simulator thread, include/Simulator.h:172-231).  Every entry point
+ *    selects the handle's device itself.
+ */
+#ifndef FLUIDSIM_AMD_H
+#define FLUIDSIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    FS_OK = 0,
+    FS_EINVAL = -1,   /* bad argument                                    */
+    FS_EHIP = -2,     /* a HIP runtime call failed                       */
+    FS_ENOMEM = -3,   /* device or host allocation failed                */
+    FS_ECOMM = -4,    /* an RCCL call failed or the communicator is bad  */
+    FS_ESTATE = -5    /* call not valid in the handle's current state    */
+};
+
+/* arithmetic type of the fields */
+enum { FS_F32 = 0, FS_F64 = 1 };
+
+/* cell types, same values as enum CellType (main.cpp:294-298) */
+enum { FS_CELL_FLUID = 0, FS_CELL_OBJECT = 1, FS_CELL_STATIC_FLUID = 2 };
+
+/* field selectors for fs3d_set_field / fs3d_get_field */
+enum { FS_FIELD_U = 0, FS_FIELD_V = 1, FS_FIELD_W = 2, FS_FIELD_DENSITY = 3, FS_FIELD_DIVERGENCE = 4 };
+
+/* visiting order of the projection sweep */
+enum {
+    FS_ORDER_RED_BLACK = 0,     /* two half-sweeps, colour (x+y+z)&1 = 0 then 1          */
+    FS_ORDER_LEXICOGRAPHIC = 1  /* the reference's order (main.cpp:235), run as
+                                   hyperplane wavefronts x+y+z = k; bit-identical
+                                   to the serial sweep, slow, for parity runs   */
+};
+
+/* stopping rule of the projection loop */
+enum {
+    FS_STOP_FIXED = 0,       /* exactly max_iters sweeps                                         */
+    FS_STOP_L1_CHANGE = 1,   /* until the L1 change of one sweep <= tol (main.cpp:105-111)       */
+    FS_STOP_L2_RESIDUAL = 2  /* until sqrt(sum r^2)/#interior <= tol with r = -div/dt, the residual of
+                                3_fluid/FluidSim.cpp:17-43 at dx = rho = 1; dt is the step length given
+                                to fs3d_advance / fs3d_update, and 1 for a bare fs3d_project          */
+};
+
+/* step variants of fs3d_advance */
+enum {
+    FS_STEP_REFERENCE = 0,   /* project, then self-advect: FluidSim::update (main.cpp:102-130)   */
+    FS_STEP_REFLECTION = 1   /* advection-reflection (Zehnder et al. 2018, Alg. 1); absent from
+                                the reference's code although its README names it               */
+};
+
+typedef struct fs3d_config {
+    int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device        */
+    int32_t dtype;        /* FS_F32 (the reference's precision) or FS_F64                         */
+    int32_t ordering;     /* FS_ORDER_*                                                           */
+    int32_t stop_mode;    /* FS_STOP_*                                                            */
+    int32_t max_iters;    /* sweep cap; the reference uses 1000 (main.cpp:108)                    */
+    int32_t check_every;  /* evaluate the stopping metric every n-th sweep (>= 1)                 */
+    int32_t step_mode;    /* FS_STEP_*                                                            */
+    int32_t local_slabs;  /* >= 1: cut this handle's planes into that many z-slabs on its own GPU
+                             (exercises the multi-GPU slab path inside one process)            */
+    double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
+    double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
+    double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */
+} fs3d_config;
+
+typedef struct fs3d_stats {
+    int64_t step;            /* steps performed since reset (Simulation::getStep)                */
+    double time;             /* simulated time since reset (Simulation::getTime)                 */
+    int32_t sweeps;          /* sweeps of the last projection                                    */
+    int32_t sweeps_step;     /* sweeps of all projections of the last step                       */
+    double metric;           /* last evaluated stopping metric (change or residual)              */
+    double ms_project;       /* device time of the last step's projections, milliseconds         */
+    double ms_advect;        /* device time of the last step's advections (+ reflection)         */
+    double ms_step;          /* device time of the whole last step                               */
+} fs3d_stats;
+
+typedef struct fs3d_sim fs3d_sim;
+
+/* library-wide ---------------------------------------------------------- */
+const char *fsamd_version(void);
+/* Fills cfg with the reference's behaviour: f32, red-black order, L1-change
+ * stop at 5.0 capped at 1000 sweeps checked every sweep, omega 1, reference step. */
+void fs3d_default_config(fs3d_config *cfg);
+
+/* lifetime -------------------------------------------------------------- */
+/* FluidSim::FluidSim (main.cpp:23-42): zero fields, one-cell Object shell.  */
+int fs3d_create(int nx, int ny, int nz, const fs3d_config *cfg, fs3d_sim **out);
+void fs3d_destroy(fs3d_sim *sim);
+/* Simulation::reset (include/Simulation.h:26-30): zero the fields, rebuild the
+ * shell mask, forget emitters, time = 0, step = 0.                         */
+int fs3d_reset(fs3d_sim *sim);
+int fs3d_set_config(fs3d_sim *sim, const fs3d_config *cfg); /* device and dtype must not change */
+int fs3d_get_config(const fs3d_sim *sim, fs3d_config *cfg);
+const char *fs3d_last_error(const fs3d_sim *sim);
+
+/* state access (the reference hands out m_density by reference, main.cpp:98-100,
+ * and reads m_vu/m_vv/m_vw slices in draw_velocity_field, :132-187) -------- */
+int fs3d_set_field(fs3d_sim *sim, int which, const void *host, size_t count);
+int fs3d_get_field(fs3d_sim *sim, int which, void *host, size_t count);
+/* One z-plane of a field (count = nx*ny), the access pattern of
+ * draw_velocity_field(..., depth) (main.cpp:135-152).                       */
+int fs3d_get_field_plane(fs3d_sim *sim, int which, int z, void *host, size_t count);
+/* m_s (main.cpp:311).  The outermost shell is always forced to Object.     */
+int fs3d_set_cell_types(fs3d_sim *sim, const uint8_t *host, size_t count);
+int fs3d_get_cell_types(fs3d_sim *sim, uint8_t *host, size_t count);
+
+/* scene (main.cpp:44-96) ------------------------------------------------- */
+/* sphere_influence(radius): emitter centred (nx/2, radius, nz/2), jet 20 along +y. */
+int fs3d_sphere_influence(fs3d_sim *sim, float radius);
+/* the same emitter with free centre and signed jet strength along y         */
+int fs3d_sphere_emitter(fs3d_sim *sim, float radius, float cx, float cy, float cz, float strength);
+/* fill_sphere_influence(radius, iter): re-stamps the density inside the sphere
+ * centred (nx/2, radius, nz/2) when iter % 100 == 0 (main.cpp:60-74).       */
+int fs3d_fill_sphere_influence(fs3d_sim *sim, float radius, int iter);
+/* the same re-stamp for an emitter with free centre                         */
+int fs3d_fill_sphere(fs3d_sim *sim, float radius, float cx, float cy, float cz, int iter);
+int fs3d_bottom_influence(fs3d_sim *sim); /* main.cpp:76-87 */
+int fs3d_clear(fs3d_sim *sim);            /* main.cpp:89-96 */
+/* Smoke source box in fractions of the resolution, density = 1 inside
+ * (Grid2::applySource, include/Grid2.h:55-61, extended by a z range).       */
+int fs3d_apply_source(fs3d_sim *sim, double xmin, double xmax, double ymin, double ymax, double zmin,
+                      double zmax);
+
+/* the step ---------------------------------------------------------------- */
+/* gauss_seidel_projection() (main.cpp:189-254): one sweep in the configured
+ * order; *change receives the L1 norm of the sweep's net velocity update.   */
+int fs3d_gauss_seidel_projection(fs3d_sim *sim, double *change);
+/* n sweeps without evaluating any metric (benchmark / smoother use).        */
+int fs3d_sweeps(fs3d_sim *sim, int n);
+/* Benchmark support: n sweeps back to back on the handle's stream, bracketed by
+ * two events on that stream; *ms receives the device time between them (the
+ * reference times whole frames with std::chrono, main.cpp:502, :541-543).    */
+int fs3d_time_sweeps(fs3d_sim *sim, int n, double *ms);
+/* The projection loop of update() (main.cpp:105-111) under the configured
+ * stopping rule; outputs may be NULL.                                       */
+int fs3d_project(fs3d_sim *sim, int *sweeps, double *metric);
+/* L2 residual of the current field and max |div| (3_fluid/FluidSim.cpp:25-43). */
+int fs3d_residual(fs3d_sim *sim, double *l2, double *max_abs_div);
+/* semi_lagrange(t_step, snapshot...) (main.cpp:256-291) applied to a snapshot
+ * of the current state, as update() calls it (main.cpp:122-129).            */
+int fs3d_semi_lagrange(fs3d_sim *sim, double t_step);
+/* update(t_step) (main.cpp:102-130) = fs3d_project + fs3d_semi_lagrange.    */
+int fs3d_update(fs3d_sim *sim, double t_step);
+/* Simulation::advance (include/Simulation.h:47): one step of the configured
+ * step_mode of length dt, then time += dt, step += 1.                       */
+int fs3d_advance(fs3d_sim *sim, double dt);
+int fs3d_get_stats(fs3d_sim *sim, fs3d_stats *out);
+/* Blocks until all work queued on the handle has finished.                  */
+int fs3d_synchronize(fs3d_sim *sim);
+
+/* z-slab decomposition over the GPUs of one node (no counterpart in the
+ * reference, which is single-process) ------------------------------------- */
+#define FS_COMM_ID_BYTES 128
+/* Rank 0 calls this and ships the bytes to all ranks by any host channel.   */
+int fsamd_comm_unique_id(uint8_t id[FS_COMM_ID_BYTES]);
+/* Collective.  Creates this rank's slab of a global nx*ny*nz_global grid:
+ * planes [z0, z1) plus halo planes, RCCL communicator over all ranks.       */
+int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config *cfg, int rank, int nranks,
+                     const uint8_t id[FS_COMM_ID_BYTES], fs3d_sim **out);
+/* Owned plane range of this handle in global coordinates.                   */
+int fs3d_slab_range(const fs3d_sim *sim, int *z0, int *z1, int *halo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDSIM_AMD_H */

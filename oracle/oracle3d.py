@@ -70,6 +70,17 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _View(np.ndarray):
+    """ndarray view onto the oracle's C arrays that keeps the owning object alive."""
+    _owner = None
+
+
+def _view(arr, owner):
+    v = arr.view(_View)
+    v._owner = owner
+    return v
+
+
 class Oracle3D:
     """The reference's 3D FluidSim (advection-reflection/main.cpp:21-442), restated on the CPU."""
 
@@ -90,7 +101,7 @@ class Oracle3D:
         p = self.lib.o3_field(self.h, which)
         ct = C.c_float if self.dtype is np.float32 else C.c_double
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(self.n,))
-        return arr.reshape(self.nz, self.ny, self.nx)
+        return _view(arr.reshape(self.nz, self.ny, self.nx), self)
 
     @property
     def u(self): return self.field(U)
@@ -105,7 +116,7 @@ class Oracle3D:
     def cells(self):
         p = self.lib.o3_cells(self.h)
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n,))
-        return arr.reshape(self.nz, self.ny, self.nx)
+        return _view(arr.reshape(self.nz, self.ny, self.nx), self)
 
     # --- reference surface ---
     def sphere_influence(self, radius):

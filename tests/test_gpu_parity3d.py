@@ -1,0 +1,309 @@
+"""GPU parity tests of the 3D step: the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs.
+
+Bar: the working precision is the reference's (fp32) and every kernel performs the oracle's
+operations in the oracle's order, so fields must be IDENTICAL (np.array_equal); where a
+reduction order differs (parallel sums) the tolerance is stated in the test.
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle3d import Oracle3D
+from tests.util3d import assert_fields_equal, make_pair, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+# cubic, non-cubic, ragged (not multiples of the 64x4 block), minimal
+SHAPES = [(16, 16, 16), (24, 48, 24), (70, 5, 6), (33, 9, 17), (3, 3, 3), (4, 3, 5), (130, 7, 4)]
+
+
+def test_scene_sphere_influence(fsamd):
+    # main.cpp:44-58 and the shell mask of the constructor (:28-33)
+    for n in (16, 32, 50):
+        o = Oracle3D(n, n, n)
+        g = fsamd.FluidSim3D(n, n, n)
+        o.sphere_influence(n / 10.0)
+        g.sphere_influence(n / 10.0)
+        assert np.array_equal(o.cells, g.cells)
+        assert_fields_equal(o, g, what=f"sphere_influence {n}")
+    o = Oracle3D(32, 32, 32)
+    g = fsamd.FluidSim3D(32, 32, 32)
+    o.sphere_influence(3.2); g.sphere_influence(3.2)
+    assert (g.cells == 0).sum() == 26858 and (g.cells == 1).sum() == 5768 and (g.cells == 2).sum() == 142
+
+
+def test_scene_bottom_influence_and_clear(fsamd):
+    o = Oracle3D(20, 12, 9)
+    g = fsamd.FluidSim3D(20, 12, 9)
+    o.sphere_influence(2.0); g.sphere_influence(2.0)
+    o.clear(); g.clear()
+    assert_fields_equal(o, g, what="clear")
+    o.bottom_influence(); g.bottom_influence()
+    assert np.array_equal(o.cells, g.cells)
+    assert_fields_equal(o, g, what="bottom_influence")
+    o.fill_sphere_influence(2.0, 100); g.fill_sphere_influence(2.0, 100)
+    o.fill_sphere_influence(2.0, 101); g.fill_sphere_influence(2.0, 101)
+    assert_fields_equal(o, g, what="fill_sphere_influence")
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_rb_sweeps_bit_exact(fsamd, shape):
+    nx, ny, nz = shape
+    o, g = make_pair(fsamd, nx, ny, nz, seed=1)
+    for it in range(3):
+        co = o.rb_sweep()
+        cg = g.gauss_seidel_projection()
+        assert_fields_equal(o, g, "uvw", what=f"rb sweep {it} {shape}")
+        # both sum |net change| in double; only the summation order differs
+        assert cg == pytest.approx(co, rel=1e-12, abs=1e-300)
+
+
+def test_rb_halfsweep_touches_only_fluid_faces(fsamd):
+    # Object cells and the boundary shell are never written (main.cpp:199, :227-232, :339)
+    o, g = make_pair(fsamd, 32, 20, 12, seed=2)
+    before = [g.get_field(k) for k in range(3)]
+    g.sweeps(2)
+    cells = g.cells
+    for k in range(3):
+        after = g.get_field(k)
+        assert np.array_equal(after[cells != 0], before[k][cells != 0])
+
+
+@pytest.mark.parametrize("omega", [0.8, 1.5])
+def test_rb_sweeps_over_relaxed(fsamd, omega):
+    o, g = make_pair(fsamd, 24, 16, 20, seed=3, omega=omega)
+    for it in range(4):
+        o.rb_sweep(omega)
+        g.sweeps(1)
+    assert_fields_equal(o, g, "uvw", what=f"omega {omega}")
+
+
+def test_residual_matches_oracle(fsamd):
+    o, g = make_pair(fsamd, 40, 24, 18, seed=4)
+    for _ in range(3):
+        l2, mx = g.residual()
+        s, omx = o.div_sumsq()
+        assert l2 == pytest.approx(o.residual_l2(), rel=1e-12)
+        assert mx == omx
+        o.rb_sweep(); g.sweeps(1)
+    # the divergence field the residual is built from
+    div = g.divergence
+    u, v, w = o.u, o.v, o.w
+    ref = (u[1:-1, 1:-1, 2:] - u[1:-1, 1:-1, 1:-1]) + (v[1:-1, 2:, 1:-1] - v[1:-1, 1:-1, 1:-1]) + \
+          (w[2:, 1:-1, 1:-1] - w[1:-1, 1:-1, 1:-1])
+    assert np.array_equal(div[1:-1, 1:-1, 1:-1], ref)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_semi_lagrange_bit_exact(fsamd, shape):
+    nx, ny, nz = shape
+    # velocities of several cells per step so that backtraces cross many cells and leave the grid
+    o, g = make_pair(fsamd, nx, ny, nz, seed=5, scale=60.0)
+    for it in range(2):
+        o.semi_lagrange(1.0 / 30.0)
+        g.semi_lagrange(1.0 / 30.0)
+        assert_fields_equal(o, g, what=f"semi_lagrange {it} {shape}")
+
+
+def test_semi_lagrange_non_finite_samples_read_as_zero(fsamd):
+    # main.cpp:430-434
+    o, g = make_pair(fsamd, 20, 14, 10, seed=6, scale=20.0)
+    for k in range(4):
+        f = o.field(k).copy()
+        f[3, 5, 7] = np.nan
+        f[6, 4, 9] = np.inf
+        f[2, 8, 11] = -np.inf
+        o.field(k)[...] = f
+        g.set_field(k, f)
+    o.semi_lagrange(0.05); g.semi_lagrange(0.05)
+    for k in range(4):
+        a, b = o.field(k), g.get_field(k)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0))
+
+
+def test_semi_lagrange_dt_zero_is_identity(fsamd):
+    o, g = make_pair(fsamd, 18, 12, 10, seed=7)
+    before = [g.get_field(k) for k in range(4)]
+    g.semi_lagrange(0.0)
+    cells = g.cells
+    for k in range(3):
+        assert np.array_equal(g.get_field(k)[cells == 0], before[k][cells == 0])
+
+
+def test_update_matches_oracle_red_black(fsamd):
+    # update() = projection loop with the reference's stopping rule + self-advection (main.cpp:102-130),
+    # both sides in red-black order
+    n = 32
+    o = Oracle3D(n, n, n)
+    g = fsamd.FluidSim3D(n, n, n)
+    o.sphere_influence(n / 10.0); g.sphere_influence(n / 10.0)
+    for step in range(4):
+        o.fill_sphere_influence(n / 10.0, step); g.fill_sphere_influence(n / 10.0, step)
+        it_o, ch_o = o.project_rb(stop_mode=1, tol=5.0, max_iter=1000)
+        o.semi_lagrange(1.0 / 30.0)
+        it_g = g.update(1.0 / 30.0)
+        assert it_g == it_o
+        assert g.stats().metric == pytest.approx(ch_o, rel=1e-10)
+        assert_fields_equal(o, g, what=f"update step {step}")
+
+
+def test_lexicographic_order_is_the_reference_sweep(fsamd):
+    # hyperplane wavefronts reproduce the serial sweep of main.cpp:235 bit for bit, and the serial
+    # fp32 change sum of main.cpp:243-249 exactly
+    o, g = make_pair(fsamd, 20, 13, 11, seed=8, ordering=1)
+    for it in range(3):
+        co = o.gauss_seidel_projection()
+        cg = g.gauss_seidel_projection()
+        assert_fields_equal(o, g, "uvw", what=f"lexicographic sweep {it}")
+        assert cg == co
+
+
+def test_lexicographic_update_reproduces_recorded_sweep_counts(fsamd):
+    # known answers recorded from the reference binary: 32^3 vortex ring, sweeps per step 67/14/12
+    n = 32
+    o = Oracle3D(n, n, n)
+    g = fsamd.FluidSim3D(n, n, n, ordering=1)
+    o.sphere_influence(n / 10.0); g.sphere_influence(n / 10.0)
+    counts = []
+    for step in range(3):
+        o.fill_sphere_influence(n / 10.0, step); g.fill_sphere_influence(n / 10.0, step)
+        it_o, _ = o.update(1.0 / 30.0)
+        counts.append(g.update(1.0 / 30.0))
+        assert counts[-1] == it_o
+        assert_fields_equal(o, g, what=f"lexicographic update {step}")
+    assert counts == [67, 14, 12]
+
+
+def reflection_step_oracle(o, dt, tol, max_iter):
+    """The reflection step restated with oracle primitives (see DESIGN.md, step driver)."""
+    o.project_rb(stop_mode=1, tol=tol, max_iter=max_iter)
+    u0 = [o.field(k).copy() for k in range(4)]
+    half = o.advect(0.5 * dt, u0, u0[:3], 0)
+    for k in range(4):
+        o.field(k)[...] = half[k]
+    tilde = [half[k].copy() for k in range(3)]
+    o.project_rb(stop_mode=1, tol=tol, max_iter=max_iter)
+    uh = [o.field(k).copy() for k in range(3)]
+    refl = [o.reflect(uh[k], tilde[k]) for k in range(3)]
+    out = o.advect(0.5 * dt, refl + [o.field(3).copy()], uh, 0)
+    for k in range(4):
+        o.field(k)[...] = out[k]
+
+
+def test_reflection_step_matches_oracle(fsamd):
+    n = 24
+    o = Oracle3D(n, n, n)
+    g = fsamd.FluidSim3D(n, n, n, step_mode=1, tol=0.5)
+    o.sphere_influence(n / 10.0); g.sphere_influence(n / 10.0)
+    for step in range(3):
+        reflection_step_oracle(o, 1.0 / 30.0, 0.5, 1000)
+        g.advance(1.0 / 30.0)
+        assert_fields_equal(o, g, what=f"reflection step {step}")
+    assert g.getStep() == 3 and g.getTime() == pytest.approx(0.1)
+
+
+def test_projection_converges_on_a_compatible_problem(fsamd):
+    # closed box, every interior face movable: the total divergence is zero, so the L2 residual
+    # (3_fluid/FluidSim.cpp:25-43) can be driven to the rounding floor.  (With an emitter the net flux
+    # through its fixed faces leaves a constant residual that no sweep can remove.)
+    o, g = make_pair(fsamd, 20, 20, 20, seed=12, masks=False, closed=True, stop_mode=2, tol=2e-8, max_iters=4000,
+                     check_every=25)
+    l2_0, mx_0 = g.residual()
+    sweeps, l2 = g.project()
+    assert sweeps < 4000 and l2 <= 2e-8 and l2 < 1e-4 * l2_0
+    assert g.residual()[1] < 1e-4
+    it_o, l2_o = o.project_rb(stop_mode=2, tol=2e-8, max_iter=4000, check_every=25)
+    assert it_o == sweeps and l2 == pytest.approx(l2_o, rel=1e-9)
+    assert_fields_equal(o, g, "uvw", what="converged projection")
+
+
+@pytest.mark.parametrize("slabs", [2, 3])
+def test_local_slabs_bitwise_equal_single_domain(fsamd, slabs):
+    # z-slab decomposition (halo planes, interface w exchange, halo refresh before advection) must not
+    # change a single bit: red-black ordering is partition independent
+    nx, ny, nz = 28, 18, 23
+    _, g1 = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0)
+    _, gs = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, local_slabs=slabs)
+    for mode in (0, 1):
+        g1.set_config(step_mode=mode, tol=1.0)
+        gs.set_config(step_mode=mode, tol=1.0)
+        for step in range(2):
+            g1.advance(0.02); gs.advance(0.02)
+            assert g1.stats().sweeps_step == gs.stats().sweeps_step
+            for k in range(4):
+                assert np.array_equal(g1.get_field(k), gs.get_field(k)), (mode, step, k)
+    a, b = g1.residual(), gs.residual()
+    assert a[1] == b[1] and a[0] == pytest.approx(b[0], rel=1e-12)
+
+
+def test_fp64_variant_matches_oracle(fsamd):
+    o, g = make_pair(fsamd, 22, 14, 12, seed=10, dtype=np.float64, scale=15.0)
+    for _ in range(2):
+        o.rb_sweep(); g.sweeps(1)
+    assert_fields_equal(o, g, "uvw", what="f64 sweeps")
+    o.semi_lagrange(1.0 / 30.0); g.semi_lagrange(1.0 / 30.0)
+    assert_fields_equal(o, g, what="f64 advection")
+
+
+def test_buoyancy_matches_oracle(fsamd):
+    o, g = make_pair(fsamd, 20, 30, 12, seed=11, buoyancy=1.0, stop_mode=0, max_iters=3)
+    o.buoyancy(0.05)
+    o.project_rb(stop_mode=0, max_iter=3)
+    o.semi_lagrange(0.05)
+    g.advance(0.05)
+    assert_fields_equal(o, g, what="buoyancy step")
+
+
+def test_error_paths(fsamd):
+    with pytest.raises(fsamd.FluidSimError):
+        fsamd.FluidSim3D(2, 8, 8)
+    with pytest.raises(fsamd.FluidSimError):
+        fsamd.FluidSim3D(8, 8, 8, omega=2.5)
+    g = fsamd.FluidSim3D(8, 8, 8)
+    with pytest.raises(fsamd.FluidSimError):
+        g.set_config(dtype=1)
+    with pytest.raises(ValueError):
+        g.set_field(0, np.zeros(5, dtype=np.float32))
+    with pytest.raises(fsamd.FluidSimError):
+        g.get_field_plane(0, 99)
+
+
+def test_reset_and_plane_access(fsamd):
+    g = fsamd.FluidSim3D(16, 12, 10)
+    g.sphere_influence(1.6)
+    g.setTimestep(1.0 / 30.0)
+    g.advance()
+    assert g.getStep() == 1
+    v = g.v
+    assert np.array_equal(g.get_field_plane(1, 4), v[4])
+    g.reset()
+    assert g.getStep() == 0 and g.getTime() == 0.0
+    assert not g.v.any() and not g.d.any()
+    assert (g.cells == 2).sum() == 0
+
+
+def test_full_size_properties_256(fsamd):
+    # BASELINE configuration size: properties that need no oracle
+    n = 256
+    g = fsamd.FluidSim3D(n, n, n, stop_mode=0, max_iters=20)
+    g.sphere_influence(n / 10.0)
+    l2_before, mx_before = g.residual()
+    g.project()
+    l2_after, _ = g.residual()
+    assert l2_after < l2_before
+    cells = g.cells
+    u_before = g.u
+    g.semi_lagrange(1.0 / 30.0)
+    # faces of non-Fluid locations are not advected (main.cpp:260)
+    assert np.array_equal(g.u[cells != 0], u_before[cells != 0])
+    # dt = 0: advection leaves Fluid faces unchanged
+    v_before = g.v
+    g.semi_lagrange(0.0)
+    assert np.array_equal(g.v, v_before)
+    # a z-slab run at full size is bitwise the same
+    gs = fsamd.FluidSim3D(n, n, n, stop_mode=0, max_iters=20, local_slabs=4)
+    gs.sphere_influence(n / 10.0)
+    gs.project(); gs.semi_lagrange(1.0 / 30.0); gs.semi_lagrange(0.0)
+    for k in range(4):
+        assert np.array_equal(g.get_field(k), gs.get_field(k))

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the 3D advection-reflection fluid step on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full fs3d_advance(): (buoyancy off) projection, half advection, projection,
+reflection, half advection of the synthetic vortex-ring scene, with the projection run to the L2
+residual of 3_fluid/FluidSim.cpp:17-43 <= 1e-6 or the reference's cap of 1000 sweeps
+(advection-reflection/main.cpp:108), checked every 8th sweep.
+
+Workloads (BASELINE.json configs):
+  N = 1   "Vortex ring 256^3 on one MI355X, GS to residual 1e-6, fp32"        (configs[1])
+  N > 1   "Vortex ring 512^3 z-slab decomposed across 2/4/8 MI355X"           (configs[2]; strong scaling)
+
+The printed JSON line carries `roofline` for the dominant kernel (the red-black half-sweep; algorithmic
+bytes = 25 B per cell per launch: read and write every face once, 12 + 12 B, plus one flag byte) and
+`cpu_baseline` (the CPU oracle, one thread, timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, datasheet peak
+SWEEP_BYTES_PER_CELL = 25.0    # per half-sweep launch, see module docstring
+DT = 1.0 / 30.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=0, help="cubic grid size override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--max-iters", type=int, default=1000)
+    ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--omega", type=float, default=1.0)
+    ap.add_argument("--step-mode", type=int, default=1, help="0 reference step, 1 advection-reflection")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, sweeps_per_step, sample_sweeps=None):
+    """The CPU oracle (a port of the reference's algorithm, red-black order, one thread) on a bounded
+    sample of the same workload: a few sweeps and the two advections + reflection of one step, scaled
+    to the sweep count the GPU run needed per step."""
+    import numpy as np
+    from oracle.oracle3d import Oracle3D
+    o = Oracle3D(n, n, n)
+    o.sphere_influence(n / 10.0)
+    cells = n ** 3
+    if sample_sweeps is None:
+        sample_sweeps = max(2, min(40, int(2.0e9 / (cells * 60))))   # about 10-20 s of sweeps
+    t = time.perf_counter()
+    o.project_rb(stop_mode=0, max_iter=sample_sweeps)
+    t_sweep = (time.perf_counter() - t) / sample_sweeps
+    s0 = [o.field(k).copy() for k in range(4)]
+    t = time.perf_counter()
+    half = o.advect(0.5 * DT, s0, s0[:3], 0)
+    refl = [o.reflect(s0[k], half[k]) for k in range(3)]
+    o.advect(0.5 * DT, refl + [half[3]], s0[:3], 0)
+    t_adv = time.perf_counter() - t
+    t_step = t_sweep * sweeps_per_step + t_adv
+    return {
+        "value": cells / t_step / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+        "sample": f"{sample_sweeps} red-black sweeps ({t_sweep * 1e3:.1f} ms each) + 2 half advections + reflection "
+                  f"({t_adv:.2f} s) of the same {n}^3 vortex ring, scaled to {sweeps_per_step:.0f} sweeps per step",
+        "ms_per_sweep": t_sweep * 1e3,
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import fsamd_loader
+    fs = fsamd_loader.load()
+
+    torch.cuda.set_device(local_rank)
+    comm_id = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only
+        box = [fs.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+
+    n = a.n or (256 if world == 1 else 512)
+    sim = fs.FluidSim3D(n, n, n, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
+                        stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
+                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode)
+    sim.sphere_influence(n / 10.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        sim.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    it = 0
+    for _ in range(a.warmup):
+        sim.fill_sphere_influence(n / 10.0, it); it += 1
+        sim.advance(DT)
+    barrier()
+    t0 = time.perf_counter()
+    sweeps = 0
+    for _ in range(a.steps):
+        sim.fill_sphere_influence(n / 10.0, it); it += 1
+        sim.advance(DT)
+        sweeps += sim.stats().sweeps_step
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = sim.stats()
+
+    # dominant kernel, timed live with HIP events on the library's stream
+    nsw = 20
+    sim.time_sweeps(4)
+    ms = sim.time_sweeps(nsw)
+    cells_local = sim.shape[0] * n * n
+    launch_s = ms * 1e-3 / (2 * nsw)
+    achieved = SWEEP_BYTES_PER_CELL * cells_local / launch_s / 1e9
+    barrier()
+
+    if rank == 0:
+        cells = n ** 3
+        ms_step = elapsed / a.steps * 1e3
+        sweeps_per_step = sweeps / a.steps
+        line = {
+            "metric": "full-step Mcells/s (advect + reflect + projection to residual 1e-6)",
+            "value": cells / (elapsed / a.steps) / 1e6,
+            "unit": "Mcells/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"vortex ring {n}^3, emitter sphere_influence(N/10), dt 1/30, "
+                            f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}, "
+                            f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, checked every {a.check_every}",
+                "grid": [n, n, n], "parallelism": f"z-slabs x{world}",
+                "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
+                "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_rb_halfsweep<float>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": SWEEP_BYTES_PER_CELL * cells_local, "launch_us": launch_s * 1e6,
+            },
+        }
+        pmc = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(str(n))
+                if rec and world == 1:
+                    line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, sweeps_per_step)
+        print(json.dumps(line), flush=True)
+    sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -321,6 +321,16 @@ void o3_rb_halfsweep(O3 *o, int colour, real omega) {
     }
 }
 
+/* The same half-sweep restricted to local planes [zb, ze) of a z-slab whose
+ * local plane 0 is global plane gz0 (colour is a global property).  Used by
+ * the multi-rank tests to emulate one slab per rank. */
+void o3_rb_halfsweep_range(O3 *o, int colour, real omega, int zb, int ze, int gz0) {
+    for (int z = zb; z < ze; z++)
+        for (int y = 1; y < o->ny - 1; y++)
+            for (int x = 1; x < o->nx - 1; x++)
+                if (((x + y + z + gz0) & 1) == colour) gsp_visit(o, x, y, z, omega);
+}
+
 /* Full red-black sweep (colour 0, then colour 1).  Returns the L1 norm of the
  * net per-face change of the sweep (the reference's metric, main.cpp:243-249)
  * accumulated in double. */

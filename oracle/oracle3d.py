@@ -50,6 +50,7 @@ def _lib(dtype):
     lib.o3_update.restype = C.c_int
     lib.o3_update.argtypes = [P, real, real, C.c_int, C.POINTER(real)]
     lib.o3_rb_halfsweep.argtypes = [P, C.c_int, real]
+    lib.o3_rb_halfsweep_range.argtypes = [P, C.c_int, real, C.c_int, C.c_int, C.c_int]
     lib.o3_rb_sweep.restype = C.c_double
     lib.o3_rb_sweep.argtypes = [P, real]
     lib.o3_div_sumsq.restype = C.c_double
@@ -155,6 +156,9 @@ class Oracle3D:
     # --- extensions ---
     def rb_halfsweep(self, colour, omega=1.0):
         self.lib.o3_rb_halfsweep(self.h, colour, omega)
+
+    def rb_halfsweep_range(self, colour, zb, ze, gz0, omega=1.0):
+        self.lib.o3_rb_halfsweep_range(self.h, colour, omega, zb, ze, gz0)
 
     def rb_sweep(self, omega=1.0):
         return float(self.lib.o3_rb_sweep(self.h, omega))

@@ -23,6 +23,8 @@
 #include "fs_comm.hpp"
 #include "fs_common.hpp"
 #include "fs_kernels3d.hpp"
+#include "fs_sweep_fused.hpp"
+#include "fs_sweep_rows.hpp"
 
 using namespace fsamd;
 
@@ -58,7 +60,7 @@ struct fs3d_sim {
     size_t esz = 4;
     int rank = 0, nranks = 1, nlocal = 1, nparts_global = 1;
     std::vector<Part> parts;
-    int cur = 0;                 // generation holding the current state
+    int curv = 0, curd = 0;      // generation holding the current velocity (u,v,w) / density
     bool cells_dirty = true, halo_dirty = true;
     double* dres = nullptr;      // 2 doubles per local part + 2 combined
     double* hres = nullptr;      // pinned mirror of the combined pair
@@ -68,6 +70,7 @@ struct fs3d_sim {
     Rccl* rccl = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     fs3d_stats stats{};
+    int num_cus = 256;
     double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
     std::string err;
 };
@@ -225,7 +228,8 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops) {
     return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
 }
 
-void* base_field_cur(fs3d_sim* s, Part& p, int k) { return p.f[s->cur][k]; }
+void* base_field_cur(fs3d_sim* s, Part& p, int k) { return p.f[k < 3 ? s->curv : s->curd][k]; }
+void* base_flags(fs3d_sim*, Part& p, int) { return p.flags; }
 void* base_tmp(fs3d_sim*, Part& p, int k) { return p.tmp[k]; }
 void* base_cells(fs3d_sim*, Part& p, int) { return p.cells; }
 
@@ -245,6 +249,8 @@ int refresh_flags(fs3d_sim* s) {
         hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, p.g, p.cells, p.flags);
     }
     SIM_HIP(hipGetLastError());
+    // the flags of a halo plane depend on cells beyond the halo: take them from the plane's owner
+    FS_TRY(exchange_halos(s, {{base_flags, 0, 1}}));
     s->cells_dirty = false;
     return FS_OK;
 }
@@ -269,8 +275,8 @@ int exchange_w_interfaces(fs3d_sim* s, int colour) {
         Part& lo = s->parts[k];
         Part& hi = s->parts[k + 1];
         const int lz_lo = lo.H + lo.own_planes(), lz_hi = hi.H;
-        T* wl = F<T>(lo, s->cur, 2);
-        T* wh = F<T>(hi, s->cur, 2);
+        T* wl = F<T>(lo, s->curv, 2);
+        T* wh = F<T>(hi, s->curv, 2);
         // the cell over the interface (global plane z1 of `lo`) has parity (x+y+z1); the upper slab
         // updated the locations of parity == colour, the lower slab the others
         hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, lo.g, wl, wh + (size_t)lz_hi * hi.g.sz, lz_lo, colour);
@@ -283,20 +289,20 @@ int exchange_w_interfaces(fs3d_sim* s, int colour) {
     const size_t bytes = (size_t)first.g.sz * s->esz;
     FS_TRY(nccl_check(s, R->GroupStart(), "ncclGroupStart"));
     if (first.has_lo) {
-        T* w = F<T>(first, s->cur, 2) + (size_t)first.H * first.g.sz;
+        T* w = F<T>(first, s->curv, 2) + (size_t)first.H * first.g.sz;
         FS_TRY(nccl_check(s, R->Send(w, bytes, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclSend"));
         FS_TRY(nccl_check(s, R->Recv(first.recv_lo, bytes, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclRecv"));
     }
     if (last.has_hi) {
-        T* w = F<T>(last, s->cur, 2) + (size_t)(last.H + last.own_planes()) * last.g.sz;
+        T* w = F<T>(last, s->curv, 2) + (size_t)(last.H + last.own_planes()) * last.g.sz;
         FS_TRY(nccl_check(s, R->Send(w, bytes, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclSend"));
         FS_TRY(nccl_check(s, R->Recv(last.recv_hi, bytes, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclRecv"));
     }
     FS_TRY(nccl_check(s, R->GroupEnd(), "ncclGroupEnd"));
     if (first.has_lo)   // I am the upper slab of this interface: take what the lower slab updated
-        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, first.g, F<T>(first, s->cur, 2), (const T*)first.recv_lo, first.H, colour ^ 1);
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, first.g, F<T>(first, s->curv, 2), (const T*)first.recv_lo, first.H, colour ^ 1);
     if (last.has_hi)
-        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, last.g, F<T>(last, s->cur, 2), (const T*)last.recv_hi, last.H + last.own_planes(), colour);
+        hipLaunchKernelGGL(k_merge_w_plane<T>, g, b, 0, s->stream, last.g, F<T>(last, s->curv, 2), (const T*)last.recv_hi, last.H + last.own_planes(), colour);
     SIM_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -307,15 +313,101 @@ int launch_halfsweep(fs3d_sim* s, int colour) {
     for (Part& p : s->parts) {
         if (p.ze - p.zb <= 0) continue;
         dim3 b(64, 4, 1), g(div_up(div_up(s->nx - 2, 2), 64), div_up(s->ny - 2, 4), p.ze - p.zb);
-        hipLaunchKernelGGL(k_rb_halfsweep<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
-                           F<T>(p, s->cur, 2), p.flags, colour, omega, p.zb, p.ze);
+        hipLaunchKernelGGL(k_rb_halfsweep<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
+                           F<T>(p, s->curv, 2), p.flags, colour, omega, p.zb, p.ze);
     }
     SIM_HIP(hipGetLastError());
     return exchange_w_interfaces<T>(s, colour);
 }
 
+// One full red-black sweep in a single pass over HBM (fs_sweep_fused.hpp): reads the current
+// velocity generation, writes the other one, then the roles swap.  Slabs recompute the two ghost
+// planes below them (and one above) instead of exchanging per colour, and refresh their halos after
+// the sweep.
+template <typename T>
+int launch_fused_sweep(fs3d_sim* s) {
+    constexpr int TX = 64, TY = 8;
+    using C = FusedTile<T, TX, TY>;
+    auto kern = k_rb_fused<T, TX, TY>;
+    SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
+    const T omega = (T)s->cfg.omega;
+    const int cv = s->curv, ov = s->curv ^ 1;
+    for (Part& p : s->parts) {
+        FusedRanges r;
+        r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
+        r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
+        const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
+        int nchunks = std::max(1, std::min(div_up(1024, tiles), p.g.nzl / 24));
+        r.zchunk = div_up(p.g.nzl, nchunks);
+        nchunks = div_up(p.g.nzl, r.zchunk);
+        dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), nchunks);
+        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
+                           F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r);
+    }
+    SIM_HIP(hipGetLastError());
+    s->curv = ov;
+    if (s->nparts_global > 1) {
+        std::vector<HaloOp> ops;
+        for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
+        FS_TRY(exchange_halos(s, ops));
+    }
+    return FS_OK;
+}
+
+// The register-resident form of the fused sweep (fs_sweep_rows.hpp); needs an even nx.
+template <typename T, int NSEG>
+int launch_rows_sweep(fs3d_sim* s) {
+    using C = RowsCfg<T, NSEG>;
+    auto kern = k_rb_rows<T, NSEG>;
+    SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
+    const T omega = (T)s->cfg.omega;
+    const int cv = s->curv, ov = s->curv ^ 1;
+    const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
+    const int nty = s->ny <= C::RY ? 1 : div_up(s->ny - 4, C::RY - 4);
+    for (Part& p : s->parts) {
+        FusedRanges r;
+        r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
+        r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
+        // z-chunks: one workgroup is resident per CU; pick the chunk count that minimises
+        // (rounds of workgroups) x (planes a workgroup marches through, its 4 overlap planes included)
+        int nchunks = 1;
+        double best = 1e300;
+        for (int c = 1; c <= std::max(1, p.g.nzl / 8); ++c) {
+            const int zc = div_up(p.g.nzl, c);
+            const int rounds = div_up(ntx * nty * div_up(p.g.nzl, zc), s->num_cus);
+            const double cost = (double)rounds * (zc + 7);
+            if (cost < best) { best = cost; nchunks = c; }
+        }
+        r.zchunk = div_up(p.g.nzl, nchunks);
+        nchunks = div_up(p.g.nzl, r.zchunk);
+        dim3 b(64, C::RY, 1), g(ntx, nty, nchunks);
+        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
+                           F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty);
+    }
+    SIM_HIP(hipGetLastError());
+    s->curv = ov;
+    if (s->nparts_global > 1) {
+        std::vector<HaloOp> ops;
+        for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
+        FS_TRY(exchange_halos(s, ops));
+    }
+    return FS_OK;
+}
+
+template <typename T>
+int launch_one_pass_sweep(fs3d_sim* s) {
+    if (s->nx % 2 == 0 && s->cfg.sweep_kernel == FS_SWEEP_FUSED) {
+        constexpr int kMaxSeg = sizeof(T) == 8 ? 2 : 4;   // LDS: 3 planes x 16 rows x 128*NSEG columns
+        if (s->nx <= 128) return launch_rows_sweep<T, 1>(s);
+        if (s->nx <= 256 || kMaxSeg == 2) return launch_rows_sweep<T, 2>(s);
+        return launch_rows_sweep<T, kMaxSeg>(s);
+    }
+    return launch_fused_sweep<T>(s);
+}
+
 template <typename T>
 int sweep_once(fs3d_sim* s) {
+    if (s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS) return launch_one_pass_sweep<T>(s);
     if (s->cfg.ordering == FS_ORDER_RED_BLACK) {
         FS_TRY(launch_halfsweep<T>(s, 0));
         return launch_halfsweep<T>(s, 1);
@@ -325,8 +417,8 @@ int sweep_once(fs3d_sim* s) {
     const T omega = (T)s->cfg.omega;
     dim3 b(64, 4, 1), g(div_up(s->ny - 2, 64), div_up(s->nz - 2, 4), 1);
     for (int k = 3; k <= (s->nx - 2) + (s->ny - 2) + (s->nz - 2); ++k)
-        hipLaunchKernelGGL(k_lexi_hyperplane<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
-                           F<T>(p, s->cur, 2), p.flags, k, omega);
+        hipLaunchKernelGGL(k_lexi_hyperplane<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
+                           F<T>(p, s->curv, 2), p.flags, k, omega);
     SIM_HIP(hipGetLastError());
     return FS_OK;
 }
@@ -359,7 +451,7 @@ template <typename T>
 int snapshot_velocity(fs3d_sim* s) {   // main.cpp:192-196; the other generation serves as the snapshot
     for (Part& p : s->parts)
         for (int k = 0; k < 3; ++k)
-            SIM_HIP(hipMemcpyAsync(p.f[s->cur ^ 1][k], p.f[s->cur][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+            SIM_HIP(hipMemcpyAsync(p.f[s->curv ^ 1][k], p.f[s->curv][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
     return FS_OK;
 }
 
@@ -367,9 +459,9 @@ template <typename T>
 int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
     if (s->cfg.ordering == FS_ORDER_LEXICOGRAPHIC) {
         Part& p = s->parts[0];
-        hipLaunchKernelGGL(k_change_serial<T>, dim3(1), dim3(64), 0, s->stream, p.g, F<T>(p, s->cur ^ 1, 0),
-                           F<T>(p, s->cur ^ 1, 1), F<T>(p, s->cur ^ 1, 2), F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
-                           F<T>(p, s->cur, 2), s->dres);
+        hipLaunchKernelGGL(k_change_serial<T>, dim3(1), dim3(64), 0, s->stream, p.g, F<T>(p, s->curv ^ 1, 0),
+                           F<T>(p, s->curv ^ 1, 1), F<T>(p, s->curv ^ 1, 2), F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
+                           F<T>(p, s->curv, 2), s->dres);
         SIM_HIP(hipGetLastError());
         SIM_HIP(hipMemcpyAsync(s->hres, s->dres, sizeof(double), hipMemcpyDeviceToHost, s->stream));
         SIM_HIP(hipStreamSynchronize(s->stream));
@@ -378,9 +470,9 @@ int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
     }
     for (int k = 0; k < s->nlocal; ++k) {
         Part& p = s->parts[k];
-        hipLaunchKernelGGL(k_change_l1<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->cur ^ 1, 0),
-                           F<T>(p, s->cur ^ 1, 1), F<T>(p, s->cur ^ 1, 2), F<T>(p, s->cur, 0), F<T>(p, s->cur, 1),
-                           F<T>(p, s->cur, 2), p.zb, p.ze, p.partials);
+        hipLaunchKernelGGL(k_change_l1<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv ^ 1, 0),
+                           F<T>(p, s->curv ^ 1, 1), F<T>(p, s->curv ^ 1, 2), F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
+                           F<T>(p, s->curv, 2), p.zb, p.ze, p.partials);
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
     }
     SIM_HIP(hipGetLastError());
@@ -391,8 +483,8 @@ template <typename T>
 int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
     for (int k = 0; k < s->nlocal; ++k) {
         Part& p = s->parts[k];
-        hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->cur, 0),
-                           F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), p.flags, p.zb, p.ze, p.partials,
+        hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv, 0),
+                           F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), p.flags, p.zb, p.ze, p.partials,
                            store_div ? (T*)p.tmp[0] : (T*)nullptr);
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
     }
@@ -408,7 +500,9 @@ int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
 // One sweep with the reference's change metric (main.cpp:189-254).
 template <typename T>
 int sweep_with_change(fs3d_sim* s, double* change) {
-    FS_TRY(snapshot_velocity<T>(s));
+    // the fused sweep leaves the previous field in the other generation: that is the snapshot
+    const bool fused = s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
+    if (!fused) FS_TRY(snapshot_velocity<T>(s));
     FS_TRY(sweep_once<T>(s));
     return change_since_snapshot<T>(s, change);
 }
@@ -457,20 +551,21 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode) {
         if (q_from_tmp) FS_TRY(exchange_halos(s, {{base_tmp, 0, s->esz}, {base_tmp, 1, s->esz}, {base_tmp, 2, s->esz}}));
     }
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
-    const int c = s->cur, o = s->cur ^ 1;
+    const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
     for (Part& p : s->parts) {
         // the owned planes, shell included, so that the new generation is complete
         const int zb = p.H, ze = p.H + p.own_planes();
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
-        const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, c, 0);
-        const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, c, 1);
-        const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, c, 2);
-        hipLaunchKernelGGL(k_advect<T>, g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, c, 3), F<T>(p, c, 0), F<T>(p, c, 1),
-                           F<T>(p, c, 2), F<T>(p, o, 0), F<T>(p, o, 1), F<T>(p, o, 2), F<T>(p, o, 3), p.flags, (T)t_step,
+        const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
+        const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
+        const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
+        hipLaunchKernelGGL(k_advect<T>, g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), F<T>(p, cv, 0), F<T>(p, cv, 1),
+                           F<T>(p, cv, 2), F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), F<T>(p, od, 3), p.flags, (T)t_step,
                            density_mode, zb, ze, s->doob);
     }
     SIM_HIP(hipGetLastError());
-    s->cur = o;
+    s->curv = ov;
+    s->curd = od;
     s->halo_dirty = s->nparts_global > 1;
     if (s->nparts_global > 1) {   // a backtrace beyond the halo cannot be served: report it
         SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -486,7 +581,7 @@ int buoyancy(fs3d_sim* s, double dt) {
     for (Part& p : s->parts) {
         if (p.ze - p.zb <= 0) continue;
         dim3 b(64, 4, 1), g(div_up(s->nx - 2, 64), div_up(s->ny - 2, 4), p.ze - p.zb);
-        hipLaunchKernelGGL(k_buoyancy<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 1), F<T>(p, s->cur, 3), p.flags, (T)dt,
+        hipLaunchKernelGGL(k_buoyancy<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 1), F<T>(p, s->curd, 3), p.flags, (T)dt,
                            (T)(0.1 * s->cfg.buoyancy), p.zb, p.ze);
     }
     SIM_HIP(hipGetLastError());
@@ -515,12 +610,12 @@ int step(fs3d_sim* s, double dt) {
         FS_TRY(advect<T>(s, 0.5 * dt, false, 0));
         for (Part& p : s->parts)
             for (int k = 0; k < 3; ++k)
-                SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->cur][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+                SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->curv][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
         FS_TRY(project<T>(s, nullptr, nullptr));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
         for (Part& p : s->parts)
-            hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->cur, 0),
-                               F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
+            hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
+                               F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
                                (const T*)p.tmp[2], (T*)p.tmp[0], (T*)p.tmp[1], (T*)p.tmp[2]);
         SIM_HIP(hipGetLastError());
         FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
@@ -543,7 +638,8 @@ void owned_range(const fs3d_sim* s, int* z0, int* z1) {
 }
 
 void* field_ptr(fs3d_sim* s, Part& p, int which) {
-    if (which >= FS_FIELD_U && which <= FS_FIELD_DENSITY) return p.f[s->cur][which];
+    if (which >= FS_FIELD_U && which <= FS_FIELD_W) return p.f[s->curv][which];
+    if (which == FS_FIELD_DENSITY) return p.f[s->curd][which];
     return p.tmp[0];
 }
 
@@ -583,7 +679,7 @@ int scatter_to(fs3d_sim* s, Part& p, const Stamp& st, int field, float scale, in
     SIM_HIP(hipMemcpyAsync(didx, st.idx.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
     SIM_HIP(hipMemcpyAsync(dval, st.val.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
     if (field >= 0)
-        hipLaunchKernelGGL(k_scatter<T>, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, dval, scale, F<T>(p, s->cur, field));
+        hipLaunchKernelGGL(k_scatter<T>, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, dval, scale, F<T>(p, field < 3 ? s->curv : s->curd, field));
     if (cell_type >= 0)
         hipLaunchKernelGGL(k_scatter_cells, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, (uint8_t)cell_type, p.cells);
     SIM_HIP(hipGetLastError());
@@ -650,14 +746,14 @@ int scene_kernel(fs3d_sim* s, int what, const int* box) {
     for (Part& p : s->parts) {
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
         if (what == 0)
-            hipLaunchKernelGGL(k_bottom_influence<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), p.cells);
+            hipLaunchKernelGGL(k_bottom_influence<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), p.cells);
         else if (what == 1)
-            hipLaunchKernelGGL(k_clear_interior<T>, g, b, 0, s->stream, p.g, F<T>(p, s->cur, 0), F<T>(p, s->cur, 1), F<T>(p, s->cur, 2), F<T>(p, s->cur, 3));
+            hipLaunchKernelGGL(k_clear_interior<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), F<T>(p, s->curd, 3));
         else {
             const int ex = box[1] - box[0], ey = box[3] - box[2], ez = box[5] - box[4];
             if (ex <= 0 || ey <= 0 || ez <= 0) continue;
             dim3 gb(div_up(ex, 64), div_up(ey, 4), ez);
-            hipLaunchKernelGGL(k_source_box<T>, gb, b, 0, s->stream, p.g, F<T>(p, s->cur, 3), box[0], box[1], box[2], box[3], box[4], box[5]);
+            hipLaunchKernelGGL(k_source_box<T>, gb, b, 0, s->stream, p.g, F<T>(p, s->curd, 3), box[0], box[1], box[2], box[3], box[4], box[5]);
         }
     }
     SIM_HIP(hipGetLastError());
@@ -673,6 +769,7 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->max_iters < 1) { *why = "max_iters must be >= 1"; return false; }
     if (c->check_every < 1) { *why = "check_every must be >= 1"; return false; }
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
+    if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
     return true;
 }
@@ -697,6 +794,8 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     else SIM_HIP(hipGetDevice(&s->device));
     DeviceGuard guard(s->device);
     if (!guard.ok) return set_err(s, FS_EHIP, "hipSetDevice failed");
+    SIM_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, s->device));
+    if (s->num_cus < 1) s->num_cus = 256;
     SIM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) SIM_HIP(hipEventCreate(&e));
     SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 2)));
@@ -738,6 +837,7 @@ void fs3d_default_config(fs3d_config* c) {
     c->check_every = 1;
     c->step_mode = FS_STEP_REFERENCE;
     c->local_slabs = 1;
+    c->sweep_kernel = FS_SWEEP_FUSED;
     c->tol = 5.0;
     c->omega = 1.0;
     c->buoyancy = 0.0;
@@ -791,7 +891,8 @@ int fs3d_reset(fs3d_sim* s) {
     SIM_GUARD(s);
     FS_TRY(zero_fields(s));
     FS_TRY(init_cells(s));
-    s->cur = 0;
+    s->curv = 0;
+    s->curd = 0;
     s->stats = fs3d_stats{};
     s->halo_dirty = true;
     SIM_HIP(hipStreamSynchronize(s->stream));

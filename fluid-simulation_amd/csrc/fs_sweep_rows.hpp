@@ -1,0 +1,232 @@
+// One full red-black sweep in one pass over HBM, register-resident variant
+// for even nx (the arrays are then 8-byte aligned per column pair).
+//
+// A workgroup is RY = 16 waves; wave r owns row y0 + r of a tile that is
+// W = 128*NSEG columns wide, lane l owns the column pairs (2l, 2l+1) + 128*sg.
+// The wave marches along z.  For its two columns a lane keeps u and w of the
+// five planes in flight in registers: the two cells a w face touches lie in
+// the same column, so w never leaves the lane, and the u faces a cell shares
+// with its x neighbours live in the neighbouring lanes and move by wave
+// shuffles.  Only v, which couples rows and therefore waves, is staged in LDS
+// (three planes).  Global traffic is one 8-byte load and one 8-byte store per
+// lane, field and plane: every face is read once and written once per sweep
+// (25 B per cell instead of the 50 B of two half-sweep launches).
+//
+// Per step t the workgroup applies colour 0 to plane t and colour 1 to plane
+// t-2; a cell visit (advection-reflection/main.cpp:198-233) touches only the
+// cell's own six faces and black on plane p needs red finished on p-1, p,
+// p+1, so the two-plane lag reproduces two separate half-sweeps exactly.
+// Tiles overlap their neighbours by two cells in x and y (and chunks by two
+// planes in z): the outer two rings of a tile go stale, the stored core is
+// exact.  Output goes to the other generation of the arrays, so workgroups
+// only read old data and need no ordering among themselves.
+#pragma once
+#include "fs_kernels3d.hpp"
+#include "fs_sweep_fused.hpp"
+
+namespace fsamd {
+
+template <typename T> struct alignas(2 * sizeof(T)) Pair { T a, b; };
+
+template <typename T, int NSEG>
+struct RowPlane {            // what a lane holds of one z-plane
+    T u[NSEG][2];
+    T w[NSEG][2];
+    uint32_t f[NSEG];        // flag bytes of the two columns, column 1 in bits 8..15
+};
+
+template <typename T, int NSEG>
+struct RowsCfg {
+    static constexpr int RY = 16;
+    static constexpr int W = 128 * NSEG;
+    static constexpr int NPV = 3;   // v planes in LDS
+    static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
+};
+
+template <typename T, int NSEG>
+__global__ void __launch_bounds__(1024)
+k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
+          T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
+          FusedRanges r, int ntx, int nty) {
+    using C = RowsCfg<T, NSEG>;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][RY][W], rows de-interleaved: even columns, then odd
+
+    const int lane = threadIdx.x, ry = threadIdx.y;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int xr0 = bx * (C::W - 4), yr0 = by * (C::RY - 4);   // tile origin; tiles overlap by 4
+    const int y = yr0 + ry;
+    const bool row_in = y < g.ny;
+    // the part of the tile this workgroup stores: everything but the two stale rings, except at the
+    // domain boundary where there is no neighbour tile
+    const int cx_lo = bx == 0 ? 0 : xr0 + 2, cx_hi = bx == ntx - 1 ? g.nx : xr0 + C::W - 2;
+    const int cy_lo = by == 0 ? 0 : yr0 + 2, cy_hi = by == nty - 1 ? g.ny : yr0 + C::RY - 2;
+    const bool row_core = y >= cy_lo && y < cy_hi;
+
+    const int c0 = blockIdx.z * r.zchunk, c1 = min(c0 + r.zchunk, g.nzl);
+    const int s1b = max(r.s1b, c0 - 1), s1e = min(r.s1e, c1);
+    const int s0b = max(r.s0b, c0 - 2), s0e = min(r.s0e, c1 + 1);
+    const int lb = max(0, c0 - 2), le = min(g.nzl, c1 + 2);
+
+    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * lane;
+    bool col_in[NSEG], col_core[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int x = xr0 + sg * 128 + 2 * lane;
+        col_in[sg] = row_in && x < g.nx;                       // nx is even: a pair is in or out as a whole
+        col_core[sg] = row_core && x >= cx_lo && x < cx_hi;   // the bounds are even: no pair straddles them
+    }
+
+    RowPlane<T, NSEG> P0, P1, P2, P3, P4;
+    Pair<T> vst[NSEG];
+
+    auto load_uf = [&](RowPlane<T, NSEG>& X, int p) {   // u, flags and the v staging registers of plane p
+        const bool pin = p >= lb && p < le;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const bool in = pin && col_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * 128 : 0;
+            Pair<T> pu = {0, 0}, pv = {0, 0};
+            uint32_t pf = FL_SELF_OBJECT | (FL_SELF_OBJECT << 8);
+            if (in) {
+                pu = *reinterpret_cast<const Pair<T>*>(ui + i);
+                pv = *reinterpret_cast<const Pair<T>*>(vi + i);
+                pf = *reinterpret_cast<const uint16_t*>(flags + i);
+            }
+            X.u[sg][0] = pu.a; X.u[sg][1] = pu.b; X.f[sg] = pf; vst[sg] = pv;
+        }
+    };
+    auto load_w = [&](RowPlane<T, NSEG>& X, int p) {
+        const bool pin = p >= lb && p < le;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const bool in = pin && col_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * 128 : 0;
+            Pair<T> pw = {0, 0};
+            if (in) pw = *reinterpret_cast<const Pair<T>*>(wi + i);
+            X.w[sg][0] = pw.a; X.w[sg][1] = pw.b;
+        }
+    };
+    auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 3 * C::NPV) % C::NPV) * C::RY + row) * C::W; };
+    auto stage_v = [&](int p) {   // v staging registers -> LDS, own row
+        T* row = vrow(p, ry);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            row[sg * 128 + lane] = vst[sg].a;
+            row[sg * 128 + 64 + lane] = vst[sg].b;
+        }
+    };
+    // One colour on plane p.  X holds plane p, Y plane p+1 (for the high-z faces).
+    auto relax = [&](RowPlane<T, NSEG>& X, RowPlane<T, NSEG>& Y, int p, int colour) {
+        const int c = (colour + xr0 + y + p + g.gz0) & 1;   // the active column of every pair of this row
+        T* v0row = vrow(p, ry);
+        T* v1row = vrow(p, ry < C::RY - 1 ? ry + 1 : ry);
+        const bool row_ok = ry < C::RY - 1;
+        T send[NSEG];
+        if (c == 0) {
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const uint32_t fl = X.f[sg] & 0xffu;
+                const bool ok = row_ok && relaxes(fl);
+                const int a = sg * 128 + lane;
+                const T u0 = X.u[sg][0], u1 = X.u[sg][1];
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[sg][0], w1 = Y.w[sg][0];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
+                if (omega != (T)1) dd = omega * dd;
+                const bool self = fl & FL_SELF_FLUID;
+                if (ok && (fl & FL_XM) && self) X.u[sg][0] = u0 + dd;
+                if (ok && (fl & FL_XP)) X.u[sg][1] = u1 - dd;
+                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
+                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[sg][0] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[sg][0] = w1 - dd;
+            }
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const uint32_t fl = (X.f[sg] >> 8) & 0xffu;
+                // the high-x face of column 2l+1 is the low-x face of the next lane's column 2l+2
+                T u1 = __shfl_down(X.u[sg][0], 1, 64);
+                bool have_hi = true;
+                if (sg + 1 < NSEG) {
+                    const T wrap = __shfl(X.u[sg + 1][0], 0, 64);
+                    if (lane == 63) u1 = wrap;
+                } else {
+                    have_hi = lane < 63;
+                }
+                const bool ok = row_ok && have_hi && relaxes(fl);
+                const int a = sg * 128 + 64 + lane;
+                const T u0 = X.u[sg][1];
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[sg][1], w1 = Y.w[sg][1];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
+                if (omega != (T)1) dd = omega * dd;
+                const bool self = fl & FL_SELF_FLUID;
+                if (ok && (fl & FL_XM) && self) X.u[sg][1] = u0 + dd;
+                send[sg] = (ok && (fl & FL_XP)) ? dd : (T)0;
+                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
+                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[sg][1] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[sg][1] = w1 - dd;
+            }
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {   // deliver -dd to the right-hand neighbour's low-x face
+                T got = __shfl_up(send[sg], 1, 64);
+                bool any = lane > 0;
+                if (sg > 0) {
+                    const T wrap = __shfl(send[sg - 1], 63, 64);
+                    if (lane == 0) { got = wrap; any = true; }
+                }
+                if (any && got != (T)0) X.u[sg][0] = X.u[sg][0] - got;
+            }
+        }
+    };
+    auto store_plane = [&](RowPlane<T, NSEG>& X, int p) {
+        const T* row = vrow(p, ry);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            if (col_core[sg]) {
+                const int64_t i = (int64_t)p * g.sz + rowoff + sg * 128;
+                *reinterpret_cast<Pair<T>*>(uo + i) = Pair<T>{X.u[sg][0], X.u[sg][1]};
+                *reinterpret_cast<Pair<T>*>(vo + i) = Pair<T>{row[sg * 128 + lane], row[sg * 128 + 64 + lane]};
+                *reinterpret_cast<Pair<T>*>(wo + i) = Pair<T>{X.w[sg][0], X.w[sg][1]};
+            }
+        }
+    };
+
+    // Step t: A = plane t-2, B = t-1, Cc = t, D = t+1, E = t+2.  u/flags/v of a plane are fetched one
+    // step before its first colour, w two steps before (it is the high-z face of the plane below).
+#define FS_ROWS_STEP(A, B, Cc, D, E)                                            \
+    {                                                                           \
+        if (t >= lb && t < le) stage_v(t);                                      \
+        load_uf(D, t + 1);                                                      \
+        load_w(E, t + 2);                                                       \
+        __syncthreads();                                                        \
+        if (t >= s0b && t < s0e) relax(Cc, D, t, 0);                            \
+        if (t - 2 >= s1b && t - 2 < s1e) relax(A, B, t - 2, 1);                 \
+        __syncthreads();                                                        \
+        if (t - 2 >= c0 && t - 2 < c1) store_plane(A, t - 2);                   \
+        ++t;                                                                    \
+        if (t > tend) break;                                                    \
+    }
+
+    int t = lb - 1;
+    const int tend = c1 + 1;
+    load_w(P3, lb);   // at the first step (t = lb-1) plane lb is "D"
+    // keep the compiler from treating never-loaded planes as undefined
+    load_w(P0, -1); load_w(P1, -1); load_w(P2, -1); load_w(P4, -1);
+    load_uf(P0, -1); load_uf(P1, -1); load_uf(P2, -1); load_uf(P3, -1); load_uf(P4, -1);
+    for (;;) {
+        FS_ROWS_STEP(P0, P1, P2, P3, P4)
+        FS_ROWS_STEP(P1, P2, P3, P4, P0)
+        FS_ROWS_STEP(P2, P3, P4, P0, P1)
+        FS_ROWS_STEP(P3, P4, P0, P1, P2)
+        FS_ROWS_STEP(P4, P0, P1, P2, P3)
+    }
+#undef FS_ROWS_STEP
+}
+
+}  // namespace fsamd

@@ -66,6 +66,14 @@ enum {
                                 to fs3d_advance / fs3d_update, and 1 for a bare fs3d_project          */
 };
 
+/* implementation of one red-black sweep (same result bit for bit) */
+enum {
+    FS_SWEEP_FUSED = 0,      /* both colours in one pass over HBM, out of place: the register-resident
+                                kernel when nx is even, else the LDS-window kernel                 */
+    FS_SWEEP_TWO_PASS = 1,   /* one in-place launch per colour                                     */
+    FS_SWEEP_FUSED_LDS = 2   /* both colours in one pass, always the LDS-window kernel             */
+};
+
 /* step variants of fs3d_advance */
 enum {
     FS_STEP_REFERENCE = 0,   /* project, then self-advect: FluidSim::update (main.cpp:102-130)   */
@@ -83,6 +91,8 @@ typedef struct fs3d_config {
     int32_t step_mode;    /* FS_STEP_*                                                            */
     int32_t local_slabs;  /* >= 1: cut this handle's planes into that many z-slabs on its own GPU
                              (exercises the multi-GPU slab path inside one process)            */
+    int32_t sweep_kernel; /* FS_SWEEP_*                                                           */
+    int32_t reserved;
     double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
     double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
     double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */

@@ -46,10 +46,12 @@ def test_scene_bottom_influence_and_clear(fsamd):
     assert_fields_equal(o, g, what="fill_sphere_influence")
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-def test_rb_sweeps_bit_exact(fsamd, shape):
+@pytest.mark.parametrize("kernel", [0, 1, 2], ids=["fused", "two_pass", "fused_lds"])
+@pytest.mark.parametrize("shape", SHAPES + [(131, 21, 40), (64, 8, 30), (66, 10, 9), (200, 40, 20), (520, 20, 12),
+                                            (128, 16, 8), (256, 28, 7), (1020, 6, 5)])
+def test_rb_sweeps_bit_exact(fsamd, shape, kernel):
     nx, ny, nz = shape
-    o, g = make_pair(fsamd, nx, ny, nz, seed=1)
+    o, g = make_pair(fsamd, nx, ny, nz, seed=1, sweep_kernel=kernel)
     for it in range(3):
         co = o.rb_sweep()
         cg = g.gauss_seidel_projection()
@@ -69,9 +71,10 @@ def test_rb_halfsweep_touches_only_fluid_faces(fsamd):
         assert np.array_equal(after[cells != 0], before[k][cells != 0])
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2], ids=["fused", "two_pass", "fused_lds"])
 @pytest.mark.parametrize("omega", [0.8, 1.5])
-def test_rb_sweeps_over_relaxed(fsamd, omega):
-    o, g = make_pair(fsamd, 24, 16, 20, seed=3, omega=omega)
+def test_rb_sweeps_over_relaxed(fsamd, omega, kernel):
+    o, g = make_pair(fsamd, 24, 16, 20, seed=3, omega=omega, sweep_kernel=kernel)
     for it in range(4):
         o.rb_sweep(omega)
         g.sweeps(1)
@@ -218,13 +221,14 @@ def test_projection_converges_on_a_compatible_problem(fsamd):
     assert_fields_equal(o, g, "uvw", what="converged projection")
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2], ids=["fused", "two_pass", "fused_lds"])
 @pytest.mark.parametrize("slabs", [2, 3])
-def test_local_slabs_bitwise_equal_single_domain(fsamd, slabs):
+def test_local_slabs_bitwise_equal_single_domain(fsamd, slabs, kernel):
     # z-slab decomposition (halo planes, interface w exchange, halo refresh before advection) must not
     # change a single bit: red-black ordering is partition independent
     nx, ny, nz = 28, 18, 23
-    _, g1 = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0)
-    _, gs = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, local_slabs=slabs)
+    _, g1 = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, sweep_kernel=1)
+    _, gs = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, local_slabs=slabs, sweep_kernel=kernel)
     for mode in (0, 1):
         g1.set_config(step_mode=mode, tol=1.0)
         gs.set_config(step_mode=mode, tol=1.0)

@@ -269,41 +269,82 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double* __restrict__
 // ---------------------------------------------------------------------------
 // Semi-Lagrangian advection (main.cpp:256-291, sampler :380-435).
 //
-// safeSample: zero outside the grid, zero on the boundary shell, zero for
-// non-finite values (main.cpp:411-435).  Coordinates are global; a sample
-// whose plane is not held by this slab raises *oob instead.
+// sample() of main.cpp:380-409 with safeSample (main.cpp:411-435) folded in:
+// same backtrace, same weight grouping, same order of the eight terms; a tap
+// reads zero outside the grid, on the boundary shell and for non-finite values.
+// Coordinates are global; a tap the reference would read but whose plane this
+// slab does not hold raises the out-of-halo flag.
+//
+// The work is split into prepare (backtrace, weights, validity bits, base
+// address), gather (eight unconditional loads from the clamped base address
+// plus fixed offsets) and combine, so that a thread has the gathers of all its
+// samples in flight together instead of one dependent round trip per tap.
+// Clamping the base into [0, n-2] never moves a tap the reference reads (such
+// a tap has both itself and its base in range).
 template <typename T>
-__device__ __forceinline__ T safe_sample(const Grid& g, const T* __restrict__ q, int x, int y, int z,
-                                         int* __restrict__ oob) {
-    if (x < 1 || y < 1 || z < 1 || x >= g.nx - 1 || y >= g.ny - 1 || z >= g.gnz - 1) return (T)0;
-    const int lz = z - g.gz0;
-    if (lz < 0 || lz >= g.nzl) { *oob = 1; return (T)0; }
-    const T val = q[gidx(g, x, y, lz)];
-    return isfinite(val) ? val : (T)0;
-}
+struct Trace {
+    T fu, fv, fw;
+    int64_t base;
+    uint32_t ok;    // bit k: tap k (order of main.cpp:400-407) is read by the reference
+    bool oob;
+};
 
-// sample() of main.cpp:380-409: same backtrace, same weight grouping, same
-// order of the eight terms.
 template <typename T>
-__device__ __forceinline__ T trace_sample(const Grid& g, const T* __restrict__ q, int x, int y, int gz, T dx,
-                                          T dy, T dz, T t_step, int* __restrict__ oob) {
+__device__ __forceinline__ Trace<T> trace_prepare(const Grid& g, int x, int y, int gz, T dx, T dy, T dz, T t_step) {
+    Trace<T> tr;
     const T px = (T)x - dx * t_step;
     const T py = (T)y - dy * t_step;
     const T pz = (T)gz - dz * t_step;
-    const T bx = floor(px), tx = bx + (T)1, fu = (px - bx) / (tx - bx);
-    const T by = floor(py), ty = by + (T)1, fv = (py - by) / (ty - by);
-    const T bz = floor(pz), tz = bz + (T)1, fw = (pz - bz) / (tz - bz);
-    const int ibx = (int)bx, itx = (int)tx, iby = (int)by, ity = (int)ty, ibz = (int)bz, itz = (int)tz;
-    const T one = (T)1;
+    const T bx = floor(px), by = floor(py), bz = floor(pz);
+    // (n - b) / (t - b) with t = b + 1: t - b is exactly 1 unless |b| >= 2^24 (2^53 in double), where
+    // the reference divides by 0 or 2; dividing by 1 is exact, so the divisions run only in that case
+    tr.fu = px - bx; tr.fv = py - by; tr.fw = pz - bz;
+    const T ex = (bx + (T)1) - bx, ey = (by + (T)1) - by, ez = (bz + (T)1) - bz;
+    if (__builtin_expect(ex != (T)1 || ey != (T)1 || ez != (T)1, 0)) {
+        tr.fu = tr.fu / ex; tr.fv = tr.fv / ey; tr.fw = tr.fw / ez;
+    }
+    const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
+    const bool x0 = ibx >= 1 && ibx < g.nx - 1, x1 = ibx >= 0 && ibx < g.nx - 2;
+    const bool y0 = iby >= 1 && iby < g.ny - 1, y1 = iby >= 0 && iby < g.ny - 2;
+    bool z0 = ibz >= 1 && ibz < g.gnz - 1, z1 = ibz >= 0 && ibz < g.gnz - 2;
+    const int lzb = ibz - g.gz0;
+    const bool h0 = lzb >= 0 && lzb < g.nzl, h1 = lzb >= -1 && lzb < g.nzl - 1;
+    tr.oob = ((z0 && !h0) || (z1 && !h1)) && (x0 || x1) && (y0 || y1);
+    z0 = z0 && h0; z1 = z1 && h1;
+    tr.ok = (uint32_t)(x0 && y0 && z0) | ((uint32_t)(x1 && y0 && z0) << 1) | ((uint32_t)(x0 && y1 && z0) << 2) |
+            ((uint32_t)(x0 && y0 && z1) << 3) | ((uint32_t)(x1 && y1 && z0) << 4) | ((uint32_t)(x1 && y0 && z1) << 5) |
+            ((uint32_t)(x0 && y1 && z1) << 6) | ((uint32_t)(x1 && y1 && z1) << 7);
+    const int cx = min(max(ibx, 0), g.nx - 2), cy = min(max(iby, 0), g.ny - 2), cz = min(max(lzb, 0), g.nzl - 2);
+    tr.base = gidx(g, cx, cy, cz);
+    return tr;
+}
+
+template <typename T> struct Taps { T s[8]; };
+
+template <typename T>
+__device__ __forceinline__ Taps<T> trace_gather(const Grid& g, const T* __restrict__ q, const Trace<T>& tr) {
+    const T* b = q + tr.base;
+    Taps<T> t;
+    t.s[0] = b[0]; t.s[1] = b[1]; t.s[2] = b[g.sy]; t.s[3] = b[g.sz];
+    t.s[4] = b[g.sy + 1]; t.s[5] = b[g.sz + 1]; t.s[6] = b[g.sz + g.sy]; t.s[7] = b[g.sz + g.sy + 1];
+    return t;
+}
+
+template <typename T>
+__device__ __forceinline__ T trace_combine(const Trace<T>& tr, const Taps<T>& t) {
+    T s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = (((tr.ok >> k) & 1u) && isfinite(t.s[k])) ? t.s[k] : (T)0;
+    const T one = (T)1, fu = tr.fu, fv = tr.fv, fw = tr.fw;
     T r = 0;
-    r += safe_sample(g, q, ibx, iby, ibz, oob) * ((one - fu) * (one - fv) * (one - fw));
-    r += safe_sample(g, q, itx, iby, ibz, oob) * ((fu) * (one - fv) * (one - fw));
-    r += safe_sample(g, q, ibx, ity, ibz, oob) * ((one - fu) * (fv) * (one - fw));
-    r += safe_sample(g, q, ibx, iby, itz, oob) * ((one - fu) * (one - fv) * (fw));
-    r += safe_sample(g, q, itx, ity, ibz, oob) * ((fu) * (fv) * (one - fw));
-    r += safe_sample(g, q, itx, iby, itz, oob) * ((fu) * (one - fv) * (fw));
-    r += safe_sample(g, q, ibx, ity, itz, oob) * ((one - fu) * (fv) * (fw));
-    r += safe_sample(g, q, itx, ity, itz, oob) * ((fu) * (fv) * (fw));
+    r += s[0] * ((one - fu) * (one - fv) * (one - fw));
+    r += s[1] * ((fu) * (one - fv) * (one - fw));
+    r += s[2] * ((one - fu) * (fv) * (one - fw));
+    r += s[3] * ((one - fu) * (one - fv) * (fw));
+    r += s[4] * ((fu) * (fv) * (one - fw));
+    r += s[5] * ((fu) * (one - fv) * (fw));
+    r += s[6] * ((one - fu) * (fv) * (fw));
+    r += s[7] * ((fu) * (fv) * (fw));
     return r;
 }
 
@@ -329,35 +370,36 @@ k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __
     const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
     if (interior) {
         const uint32_t fl = flags[i];
-        int oob = 0;
         const T four = (T)4, two = (T)2;
-        if (fl & FL_SELF_FLUID) {
-            T dx, dy, dz;
-            // main.cpp:261-266
-            dx = U[i];
-            dy = (V[i] + V[i - 1] + V[i + g.sy] + V[i - 1 + g.sy]) / four;
-            dz = (W[i] + W[i - 1] + W[i + g.sz] + W[i - 1 + g.sz]) / four;
-            nu = trace_sample(g, qu, x, y, gz, dx, dy, dz, t_step, &oob);
-            // main.cpp:269-274
-            dx = (U[i] + U[i - g.sy] + U[i + 1] + U[i + 1 - g.sy]) / four;
-            dy = V[i];
-            dz = (W[i] + W[i - g.sy] + W[i + g.sz] + W[i - g.sy + g.sz]) / four;
-            nv = trace_sample(g, qv, x, y, gz, dx, dy, dz, t_step, &oob);
-            // main.cpp:276-281
-            dx = (U[i] + U[i - g.sz] + U[i + 1] + U[i + 1 - g.sz]) / four;
-            dy = (V[i] + V[i - g.sz] + V[i + g.sy] + V[i + g.sy - g.sz]) / four;
-            dz = W[i];
-            nw = trace_sample(g, qw, x, y, gz, dx, dy, dz, t_step, &oob);
+        const bool fluid = fl & FL_SELF_FLUID;
+        // the 13-point neighbourhood of the carrying velocity
+        const T u_c = U[i], u_xp = U[i + 1], u_ym = U[i - g.sy], u_xp_ym = U[i + 1 - g.sy], u_zm = U[i - g.sz],
+                u_xp_zm = U[i + 1 - g.sz];
+        const T v_c = V[i], v_xm = V[i - 1], v_yp = V[i + g.sy], v_xm_yp = V[i - 1 + g.sy], v_zm = V[i - g.sz],
+                v_yp_zm = V[i + g.sy - g.sz];
+        const T w_c = W[i], w_xm = W[i - 1], w_zp = W[i + g.sz], w_xm_zp = W[i - 1 + g.sz], w_ym = W[i - g.sy],
+                w_ym_zp = W[i - g.sy + g.sz];
+        // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
+        const Trace<T> tu = trace_prepare(g, x, y, gz, u_c, (v_c + v_xm + v_yp + v_xm_yp) / four,
+                                          (w_c + w_xm + w_zp + w_xm_zp) / four, t_step);
+        const Trace<T> tv = trace_prepare(g, x, y, gz, (u_c + u_ym + u_xp + u_xp_ym) / four, v_c,
+                                          (w_c + w_ym + w_zp + w_ym_zp) / four, t_step);
+        const Trace<T> tw = trace_prepare(g, x, y, gz, (u_c + u_zm + u_xp + u_xp_zm) / four,
+                                          (v_c + v_zm + v_yp + v_yp_zm) / four, w_c, t_step);
+        bool oob = fluid && (tu.oob || tv.oob || tw.oob);
+        const Taps<T> gu = trace_gather(g, qu, tu), gv = trace_gather(g, qv, tv), gw = trace_gather(g, qw, tw);
+        const T su = trace_combine(tu, gu), sv = trace_combine(tv, gv), sw = trace_combine(tw, gw);
+        if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
+        // main.cpp:284-289
+        T uc, vc, wc;
+        if (density_mode == 1) {
+            uc = (nu + u_xp) / two; vc = (nv + v_yp) / two; wc = (nw + w_zp) / two;
+        } else {
+            uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
         }
-        if (!(fl & FL_SELF_OBJECT)) {   // main.cpp:284-289
-            T uc, vc, wc;
-            if (density_mode == 1) {
-                uc = (nu + U[i + 1]) / two; vc = (nv + V[i + g.sy]) / two; wc = (nw + W[i + g.sz]) / two;
-            } else {
-                uc = (U[i] + U[i + 1]) / two; vc = (V[i] + V[i + g.sy]) / two; wc = (W[i] + W[i + g.sz]) / two;
-            }
-            nd = trace_sample(g, qd, x, y, gz, uc, vc, wc, t_step, &oob);
-        }
+        const Trace<T> td = trace_prepare(g, x, y, gz, uc, vc, wc, t_step);
+        const T sd = trace_combine(td, trace_gather(g, qd, td));
+        if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || td.oob; }
         if (oob) *oob_flag = 1;
     }
     ou[i] = nu; ov[i] = nv; ow[i] = nw; od[i] = nd;

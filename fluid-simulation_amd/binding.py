@@ -40,6 +40,8 @@ EXPORTS = [
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fsamd_comm_unique_id",
     "fs3d_create_slab", "fs3d_slab_range",
+    "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
+    "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
 ]
 
 
@@ -112,6 +114,17 @@ def load_library(path=None):
         "fsamd_comm_unique_id": (I, [P]),
         "fs3d_create_slab": (I, [I, I, I, C.POINTER(Config), I, I, P, C.POINTER(P)]),
         "fs3d_slab_range": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
+        "fs2d_create": (I, [I, I, I, C.POINTER(P)]),
+        "fs2d_destroy": (None, [P]),
+        "fs2d_last_error": (C.c_char_p, [P]),
+        "fs2d_reset": (I, [P]),
+        "fs2d_set_params": (I, [P, D, D, I, I, I, I]),
+        "fs2d_get_info": (I, [P, C.POINTER(D), C.POINTER(D), C.POINTER(C.c_uint64), C.POINTER(I), C.POINTER(D)]),
+        "fs2d_field_size": (I, [P, I, C.POINTER(I), C.POINTER(I)]),
+        "fs2d_get_field": (I, [P, I, P, C.c_size_t]),
+        "fs2d_set_field": (I, [P, I, P, C.c_size_t]),
+        "fs2d_advance": (I, [P]),
+        "fs2d_stage": (I, [P, I]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export it
@@ -312,3 +325,88 @@ class FluidSim3D:
 
     def synchronize(self):
         self._chk(self.lib.fs3d_synchronize(self.h))
+
+
+class FluidSim2D:
+    """The reference's 2D smoke solver (class FluidSim, 3_fluid/FluidSim.{h,cpp}) on the GPU, fp64.
+    Fields are numpy arrays indexed [x, y] like the reference's Array2d(x, y)."""
+
+    DENSITY, PRESSURE, DIVERGENCE, VORTICITY, U, V, FORCE_X, FORCE_Y = range(8)
+
+    def __init__(self, res_x=128, res_y=192, device=-1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.fs2d_create(res_x, res_y, device, C.byref(h))
+        self.h = h
+        if rc != FS_OK:
+            msg = self.lib.fs2d_last_error(h).decode() if h else "invalid argument"
+            if h:
+                self.lib.fs2d_destroy(h)
+            self.h = None
+            raise FluidSimError(f"fs2d_create failed ({rc}): {msg}")
+        self.res_x, self.res_y = res_x, res_y
+        self._wind, self._mac, self._ordering = False, True, ORDER_LEXICOGRAPHIC
+
+    def _chk(self, rc):
+        if rc != FS_OK:
+            raise FluidSimError(f"fluidsim_amd 2D call failed ({rc}): {self.lib.fs2d_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fs2d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shape(self, which):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.lib.fs2d_field_size(self.h, which, C.byref(a), C.byref(b)))
+        return (a.value, b.value)
+
+    def get(self, which):
+        out = np.empty(self.shape(which), dtype=np.float64)
+        self._chk(self.lib.fs2d_get_field(self.h, which, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def set(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.shape != self.shape(which):
+            raise ValueError("field shape mismatch")
+        self._chk(self.lib.fs2d_set_field(self.h, which, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def params(self, dt=0.0, acc=0.0, iters=0, wind=None, maccormack=None, ordering=None):
+        self._wind = self._wind if wind is None else bool(wind)
+        self._mac = self._mac if maccormack is None else bool(maccormack)
+        self._ordering = self._ordering if ordering is None else ordering
+        self._chk(self.lib.fs2d_set_params(self.h, dt, acc, iters, int(self._wind), int(self._mac), self._ordering))
+
+    # the reference's setters (3_fluid/FluidSim.h:258-277, include/Simulation.h:58)
+    def setTimestep(self, t): self.params(dt=t)
+    def setAccuracy(self, acc): self.params(acc=acc)
+    def setIteration(self, n): self.params(iters=n)
+    def setWind(self, w): self.params(wind=w)
+    def setMacCormack(self, m): self.params(maccormack=m)
+
+    def info(self):
+        dt, t, res = C.c_double(), C.c_double(), C.c_double()
+        step, it = C.c_uint64(), C.c_int()
+        self._chk(self.lib.fs2d_get_info(self.h, C.byref(dt), C.byref(t), C.byref(step), C.byref(it), C.byref(res)))
+        return {"dt": dt.value, "time": t.value, "step": step.value, "last_iters": it.value, "last_residual": res.value}
+
+    def getTimestep(self): return self.info()["dt"]
+    def getTime(self): return self.info()["time"]
+    def getStep(self): return self.info()["step"]
+
+    def reset(self):
+        self._chk(self.lib.fs2d_reset(self.h))
+
+    def advance(self):
+        self._chk(self.lib.fs2d_advance(self.h))
+        return False
+
+    def stage(self, op):
+        self._chk(self.lib.fs2d_stage(self.h, op))

@@ -195,6 +195,60 @@ int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config *cfg, int 
 /* Owned plane range of this handle in global coordinates.                   */
 int fs3d_slab_range(const fs3d_sim *sim, int *z0, int *z1, int *halo);
 
+/* ------------------------------------------------------------------------
+ * The 2D fp64 smoke solver: class FluidSim of 3_fluid/FluidSim.h:11-303 and
+ * 3_fluid/FluidSim.cpp:1-389.  Fields use the reference's Array2T layout
+ * (include/Array2T.h:59-63): element (x, y) at data[x*size1 + y], doubles.
+ * ---------------------------------------------------------------------- */
+enum {
+    FS2D_DENSITY = 0, FS2D_PRESSURE = 1, FS2D_DIVERGENCE = 2, FS2D_VORTICITY = 3,   /* res_x * res_y          */
+    FS2D_U = 4, FS2D_FORCE_X = 6,                                                   /* (res_x + 1) * res_y    */
+    FS2D_V = 5, FS2D_FORCE_Y = 7                                                    /* res_x * (res_y + 1)    */
+};
+
+/* single stages of advance(), for stage-wise use and tests */
+enum {
+    FS2D_APPLY_SOURCE = 0,       /* Grid2::applySource(0.45, 0.55, 0.1, 0.15), include/Grid2.h:55-61 */
+    FS2D_ADD_BUOYANCY = 1,       /* FluidSim.h:109-118 */
+    FS2D_ADD_WIND = 2,           /* FluidSim.h:120-134 */
+    FS2D_ADD_FORCE = 3,          /* FluidSim.h:136-148 */
+    FS2D_SOLVE_PRESSURE = 4,     /* FluidSim.h:150-167, lexicographic Poisson sweeps */
+    FS2D_ADVECT_VALUES = 5,      /* FluidSim.cpp:68-85 (semi-Lagrange, MacCormack update + clamp) */
+    FS2D_SET_NEUMANN = 6,        /* FluidSim.h:169-187 */
+    FS2D_SET_ZERO = 7,           /* FluidSim.h:189-207 */
+    FS2D_COMPUTE_DIVERGENCE = 8, /* FluidSim.h:209-218 */
+    FS2D_COPY_BORDER = 9,        /* FluidSim.h:231-243 */
+    FS2D_SOLVE_POISSON = 10,     /* FluidSim.cpp:6-48 */
+    FS2D_CORRECT_VELOCITY = 11,  /* FluidSim.cpp:50-66 */
+    FS2D_COMPUTE_VORTICITY = 12, /* FluidSim.h:220-229 */
+    FS2D_RESET_FORCE = 13,       /* FluidSim.h:89 */
+    FS2D_SOLVE_PRESSURE_RB = 14, /* the same with red-black Poisson sweeps */
+    FS2D_SOLVE_POISSON_RB = 15
+};
+
+typedef struct fs2d_sim fs2d_sim;
+
+/* FluidSim::init (FluidSim.h:15-41) for a free resolution (the reference fixes 128 x 192): dx = 1,
+ * dt = 0.005*sqrt((res_x+res_y)/2), accuracy 1e-5, 1000 iterations, MacCormack on, wind off; then reset. */
+int fs2d_create(int res_x, int res_y, int device, fs2d_sim **out);
+void fs2d_destroy(fs2d_sim *sim);
+const char *fs2d_last_error(const fs2d_sim *sim);
+/* Simulation::reset (include/Simulation.h:26-30) + FluidSim::resetMembers (FluidSim.h:43-50) */
+int fs2d_reset(fs2d_sim *sim);
+/* setTimestep / setAccuracy / setIteration / setWind / setMacCormack (Simulation.h:58, FluidSim.h:263-266);
+ * dt, acc, iter <= 0 leave the value unchanged.  ordering: FS_ORDER_LEXICOGRAPHIC (the reference's Poisson
+ * sweep order, bit-identical, default) or FS_ORDER_RED_BLACK (parallel, same tolerance). */
+int fs2d_set_params(fs2d_sim *sim, double dt, double acc, int iter, int wind, int maccormack, int ordering);
+/* getTimestep / getTime / getStep, plus the iterations and residual of the last Poisson solve */
+int fs2d_get_info(fs2d_sim *sim, double *dt, double *time, uint64_t *step, int *last_iters, double *last_residual);
+int fs2d_field_size(const fs2d_sim *sim, int which, int *size0, int *size1);
+/* Grid2::x() / MACGrid2::x(), y() (include/Grid2.h:20-22, include/MACGrid2.h:19-20) as whole arrays */
+int fs2d_get_field(fs2d_sim *sim, int which, double *host, size_t count);
+int fs2d_set_field(fs2d_sim *sim, int which, const double *host, size_t count);
+/* FluidSim::advance (FluidSim.h:71-96) */
+int fs2d_advance(fs2d_sim *sim);
+int fs2d_stage(fs2d_sim *sim, int stage);
+
 #ifdef __cplusplus
 }
 #endif

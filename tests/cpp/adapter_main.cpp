@@ -3,6 +3,7 @@
 // fill_sphere_influence(RES_X/10, iter); update(1/30).  Writes u,v,w,density after the last step.
 #include <cstdio>
 #include <cstdlib>
+#include <fsamd/FluidSim2D.hpp>
 #include <fsamd/FluidSim3D.hpp>
 
 int main(int argc, char** argv) {
@@ -37,6 +38,15 @@ int main(int argc, char** argv) {
                s2.getStep(), s2.getTime(), diff, mx);
         s2.reset();
         printf("after reset: step %lu time %.1f\n", s2.getStep(), s2.getTime());
+        // the 2D solver behind the same interface (3_fluid/main.cpp drives it through Simulator)
+        fsamd::FluidSim2DSimulation<> s3(32, 48);
+        for (int k = 0; k < 3; ++k) s3.advance();
+        s3.selectField(0);
+        s3.updateRenderGeometry();
+        double mass = 0;
+        for (double v : s3.renderField().data) mass += v;
+        printf("2D run: step %lu time %.6f dt %.6f density sum %.9f u(16,10) %.9e\n", s3.getStep(), s3.getTime(),
+               s3.getTimestep(), mass, s3.field(FS2D_U)(16, 10));
         return diff == 0 ? 0 : 2;
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());

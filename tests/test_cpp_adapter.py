@@ -34,3 +34,12 @@ def test_adapter_reproduces_oracle(tmp_path):
         o.semi_lagrange(np.float32(1.0 / 30.0))
     for k in range(4):
         assert np.array_equal(got[k], o.field(k)), f"field {k}"
+    # the 2D solver through the Simulation-shaped adapter
+    from oracle import oracle2d as o2
+    ref = o2.Oracle2D(32, 48)
+    for _ in range(3):
+        ref.advance()
+    line = [l for l in res.stdout.splitlines() if l.startswith("2D run:")][0].split()
+    assert line[3] == "3" and float(line[7]) == pytest.approx(ref.dt, abs=1e-6)
+    assert float(line[10]) == pytest.approx(ref.get(o2.DENSITY).sum(), abs=1e-8)
+    assert float(line[12]) == pytest.approx(ref.get(o2.U)[16, 10], rel=1e-8, abs=1e-15)

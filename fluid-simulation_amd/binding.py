@@ -38,7 +38,7 @@ EXPORTS = [
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
-    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fsamd_comm_unique_id",
+    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fsamd_comm_unique_id", "fsamd_comm_selftest",
     "fs3d_create_slab", "fs3d_slab_range",
     "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
     "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
@@ -112,6 +112,7 @@ def load_library(path=None):
         "fs3d_get_stats": (I, [P, C.POINTER(Stats)]),
         "fs3d_synchronize": (I, [P]),
         "fsamd_comm_unique_id": (I, [P]),
+        "fsamd_comm_selftest": (I, [I]),
         "fs3d_create_slab": (I, [I, I, I, C.POINTER(Config), I, I, P, C.POINTER(P)]),
         "fs3d_slab_range": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
         "fs2d_create": (I, [I, I, I, C.POINTER(P)]),

@@ -857,6 +857,52 @@ int fsamd_comm_unique_id(uint8_t id[FS_COMM_ID_BYTES]) {
     return FS_OK;
 }
 
+// Loopback check of the RCCL binding on one GPU: a one-rank communicator, an all-reduce and a grouped
+// send/receive to itself on a private stream.  Returns FS_OK when the collective library could be
+// loaded, every call succeeded and the data came back intact.
+int fsamd_comm_selftest(int device) {
+    std::string err;
+    Rccl* R = Rccl::get(err);
+    if (!R) return FS_ECOMM;
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return FS_EHIP;
+    DeviceGuard guard(dev);
+    if (!guard.ok) return FS_EHIP;
+    ncclUniqueId uid;
+    if (R->GetUniqueId(&uid) != ncclSuccess) return FS_ECOMM;
+    ncclComm_t comm = nullptr;
+    if (R->CommInitRank(&comm, 1, uid, 0) != ncclSuccess) return FS_ECOMM;
+    int rc = FS_OK;
+    hipStream_t st = nullptr;
+    double* d = nullptr;
+    const int n = 1 << 16;
+    std::vector<double> h(2 * n + 2);
+    for (int i = 0; i < n; ++i) h[i] = 0.5 * i;
+    h[2 * n] = 3.0; h[2 * n + 1] = 7.0;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = FS_EHIP;
+    if (rc == FS_OK) {
+        bool ok = R->AllReduce(d + 2 * n, d + 2 * n, 1, ncclDouble, ncclSum, comm, st) == ncclSuccess;
+        ok = ok && R->AllReduce(d + 2 * n + 1, d + 2 * n + 1, 1, ncclDouble, ncclMax, comm, st) == ncclSuccess;
+        ok = ok && R->GroupStart() == ncclSuccess;
+        ok = ok && R->Send(d, n * sizeof(double), ncclUint8, 0, comm, st) == ncclSuccess;
+        ok = ok && R->Recv(d + n, n * sizeof(double), ncclUint8, 0, comm, st) == ncclSuccess;
+        ok = ok && R->GroupEnd() == ncclSuccess;
+        if (!ok) rc = FS_ECOMM;
+    }
+    if (rc == FS_OK && (hipStreamSynchronize(st) != hipSuccess ||
+                        hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) rc = FS_EHIP;
+    if (rc == FS_OK) {
+        for (int i = 0; i < n; ++i) if (h[n + i] != 0.5 * i) rc = FS_ECOMM;
+        if (h[2 * n] != 3.0 || h[2 * n + 1] != 7.0) rc = FS_ECOMM;
+    }
+    (void)hipFree(d);
+    if (st) (void)hipStreamDestroy(st);
+    (void)R->CommDestroy(comm);
+    return rc;
+}
+
 int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config* cfg, int rank, int nranks,
                      const uint8_t id[FS_COMM_ID_BYTES], fs3d_sim** out) {
     if (nranks < 1 || (nranks > 1 && !id)) return FS_EINVAL;

@@ -188,6 +188,9 @@ int fs3d_synchronize(fs3d_sim *sim);
 #define FS_COMM_ID_BYTES 128
 /* Rank 0 calls this and ships the bytes to all ranks by any host channel.   */
 int fsamd_comm_unique_id(uint8_t id[FS_COMM_ID_BYTES]);
+/* Loopback check of the RCCL binding on one GPU (one-rank communicator, all-reduce, grouped send and
+ * receive to itself); FS_OK when every call succeeded and the data came back intact.                */
+int fsamd_comm_selftest(int device);
 /* Collective.  Creates this rank's slab of a global nx*ny*nz_global grid:
  * planes [z0, z1) plus halo planes, RCCL communicator over all ranks.       */
 int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config *cfg, int rank, int nranks,

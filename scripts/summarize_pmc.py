@@ -24,7 +24,8 @@ for n in map(int, sys.argv[2:]):
     for k, d in sorted(per.items()):
         f, nf = d.get("FETCH_SIZE", (0, 0)); w, _ = d.get("WRITE_SIZE", (0, 0))
         print(f"{k[:45]:45s} {nf:8d} {f:12.4g} {2 * f:12.4g} {w:12.4g} {(2 * f + w) / cells:10.2f}")
-        if "k_rb_halfsweep" in k:
-            out[str(n)] = {"fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
-                           "hbm_bytes_per_cell": (2 * f + w) / cells, "algorithmic_bytes_per_cell": 25.0}
+        if "k_rb_rows" in k or "k_rb_fused" in k:   # one launch = one full red-black sweep
+            out[str(n)] = {"kernel": k, "fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
+                           "hbm_bytes_per_cell": (2 * f + w) / cells, "algorithmic_bytes_per_cell": 50.0,
+                           "one_pass_model_bytes_per_cell": 25.0}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "sweep_traffic.json"), "w"), indent=1)

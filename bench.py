@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--check-every", type=int, default=8)
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--step-mode", type=int, default=1, help="0 reference step, 1 advection-reflection")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f32 = the reference's precision")
+    ap.add_argument("--scene", choices=["vortex_ring", "ring_collision", "smoke_plume"], default="vortex_ring")
+    ap.add_argument("--grid", type=str, default="", help="nx,ny,nz override (e.g. 256,512,256 for the plume)")
     return ap.parse_args()
 
 
@@ -104,11 +107,16 @@ def main():
         dist.broadcast_object_list(box, src=0)
         comm_id = box[0]
 
+    import fluid_simulation_amd.scenes as scenes
     n = a.n or (256 if world == 1 else 512)
-    sim = fs.FluidSim3D(n, n, n, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
+    nx, ny, nz = (int(v) for v in a.grid.split(",")) if a.grid else (n, n, n)
+    sim = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
+                        dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
-                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode)
-    sim.sphere_influence(n / 10.0)
+                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode,
+                        buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
+    scene_init, scene_step = scenes.SCENES[a.scene]
+    scene_init(sim)
 
     def barrier():
         torch.cuda.synchronize()
@@ -118,13 +126,13 @@ def main():
 
     it = 0
     for _ in range(a.warmup):
-        sim.fill_sphere_influence(n / 10.0, it); it += 1
+        scene_step(sim, it); it += 1
         sim.advance(DT)
     barrier()
     t0 = time.perf_counter()
     sweeps = 0
     for _ in range(a.steps):
-        sim.fill_sphere_influence(n / 10.0, it); it += 1
+        scene_step(sim, it); it += 1
         sim.advance(DT)
         sweeps += sim.stats().sweeps_step
     barrier()
@@ -139,13 +147,15 @@ def main():
     nsw = 20
     sim.time_sweeps(4)
     ms = sim.time_sweeps(nsw)
-    cells_local = sim.shape[0] * n * n
+    cells_local = sim.shape[0] * ny * nx
     launch_s = ms * 1e-3 / nsw           # one launch per full sweep
-    achieved = SWEEP_BYTES_PER_CELL * cells_local / launch_s / 1e9
+    esz_scale = 2.0 if a.dtype == "f64" else 1.0   # 8-byte faces: 2 x (24 + 24) + 2 flag bytes ~ 98 B
+    sweep_bytes = (48.0 * esz_scale + 2.0)
+    achieved = sweep_bytes * cells_local / launch_s / 1e9
     barrier()
 
     if rank == 0:
-        cells = n ** 3
+        cells = nx * ny * nz
         ms_step = elapsed / a.steps * 1e3
         sweeps_per_step = sweeps / a.steps
         line = {
@@ -156,34 +166,35 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": a.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"vortex ring {n}^3, emitter sphere_influence(N/10), dt 1/30, "
+                "workload": f"{a.scene.replace('_', ' ')} {nx}x{ny}x{nz}, dt 1/30, "
                             f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}, "
                             f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, checked every {a.check_every}",
-                "grid": [n, n, n], "parallelism": f"z-slabs x{world}",
+                "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}",
                 "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
                 "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_rb_rows<float> (one-pass red-black sweep)", "achieved": achieved,
+                "bound": "hbm", "kernel": f"k_rb_rows<{'double' if a.dtype == 'f64' else 'float'}> (one-pass red-black sweep)",
+                "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": SWEEP_BYTES_PER_CELL * cells_local, "launch_us": launch_s * 1e6,
+                "bytes_per_launch": sweep_bytes * cells_local, "launch_us": launch_s * 1e6,
                 "blocking_factor": 2,
-                "hbm_model_bytes_per_launch": FUSED_HBM_BYTES_PER_CELL * cells_local,
-                "hbm_model_rate": FUSED_HBM_BYTES_PER_CELL * cells_local / launch_s / 1e9,
+                "hbm_model_bytes_per_launch": 0.5 * sweep_bytes * cells_local,
+                "hbm_model_rate": 0.5 * sweep_bytes * cells_local / launch_s / 1e9,
             },
         }
         pmc = os.path.join(ROOT, "profiles", "sweep_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(str(n))
-                if rec and world == 1:
+                if rec and world == 1 and a.dtype == "f32" and not a.grid:
                     line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
             except Exception:
                 pass
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.scene == "vortex_ring" and not a.grid and a.dtype == "f32":
             line["cpu_baseline"] = cpu_baseline(n, sweeps_per_step)
         print(json.dumps(line), flush=True)
     sim.close()

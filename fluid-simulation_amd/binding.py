@@ -35,7 +35,7 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     "fsamd_version", "fs3d_default_config", "fs3d_create", "fs3d_destroy", "fs3d_reset", "fs3d_set_config",
     "fs3d_get_config", "fs3d_last_error", "fs3d_set_field", "fs3d_get_field", "fs3d_get_field_plane",
-    "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter",
+    "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fsamd_comm_unique_id", "fsamd_comm_selftest",
@@ -96,6 +96,7 @@ def load_library(path=None):
         "fs3d_get_cell_types": (I, [P, P, C.c_size_t]),
         "fs3d_sphere_influence": (I, [P, F]),
         "fs3d_sphere_emitter": (I, [P, F, F, F, F, F]),
+        "fs3d_solid_sphere": (I, [P, F, F, F, F]),
         "fs3d_fill_sphere_influence": (I, [P, F, I]),
         "fs3d_fill_sphere": (I, [P, F, F, F, F, I]),
         "fs3d_bottom_influence": (I, [P]),
@@ -255,6 +256,9 @@ class FluidSim3D:
 
     def sphere_emitter(self, radius, cx, cy, cz, strength):
         self._chk(self.lib.fs3d_sphere_emitter(self.h, radius, cx, cy, cz, strength))
+
+    def solid_sphere(self, radius, cx, cy, cz):
+        self._chk(self.lib.fs3d_solid_sphere(self.h, radius, cx, cy, cz))
 
     def fill_sphere_influence(self, radius, it):
         self._chk(self.lib.fs3d_fill_sphere_influence(self.h, radius, it))

@@ -1064,6 +1064,18 @@ int fs3d_sphere_emitter(fs3d_sim* s, float radius, float cx, float cy, float cz,
     return DISPATCH(s, sphere_emitter, s, radius, cx, cy, cz, strength);
 }
 
+int fs3d_solid_sphere(fs3d_sim* s, float radius, float cx, float cy, float cz) {
+    SIM_GUARD(s);
+    if (!(radius > 0)) return set_err(s, FS_EINVAL, "radius must be positive");
+    for (Part& p : s->parts) {
+        Stamp st;
+        sphere_cells(s, p, radius, cx, cy, cz, &st);
+        FS_TRY(DISPATCH(s, scatter_to, s, p, st, -1, 0.0f, FS_CELL_OBJECT));
+    }
+    s->cells_dirty = true;
+    return FS_OK;
+}
+
 int fs3d_sphere_influence(fs3d_sim* s, float radius) {
     if (!s) return FS_EINVAL;
     return fs3d_sphere_emitter(s, radius, s->nx / 2.0f, radius, s->nz / 2.0f, 20.0f);   // main.cpp:46-55

@@ -144,6 +144,9 @@ int fs3d_get_cell_types(fs3d_sim *sim, uint8_t *host, size_t count);
 int fs3d_sphere_influence(fs3d_sim *sim, float radius);
 /* the same emitter with free centre and signed jet strength along y         */
 int fs3d_sphere_emitter(fs3d_sim *sim, float radius, float cx, float cy, float cz, float strength);
+/* Interior obstacle: the cells inside the sphere (same distance test as main.cpp:50-51) become Object.
+ * The reference's mask supports interior Object cells (main.cpp:199, :210-215) but never creates any. */
+int fs3d_solid_sphere(fs3d_sim *sim, float radius, float cx, float cy, float cz);
 /* fill_sphere_influence(radius, iter): re-stamps the density inside the sphere
  * centred (nx/2, radius, nz/2) when iter % 100 == 0 (main.cpp:60-74).       */
 int fs3d_fill_sphere_influence(fs3d_sim *sim, float radius, int iter);

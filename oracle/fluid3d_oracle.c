@@ -122,6 +122,23 @@ void o3_sphere_influence(O3 *o, float radius) {
     o3_sphere_emitter(o, radius, o->nx / 2.0f, radius, o->nz / 2.0f, 20.0f);
 }
 
+/* Interior obstacle (extension): same distance test, cells become Object. */
+void o3_solid_sphere(O3 *o, float radius, float cx, float cy, float cz) {
+    FOR_INTERIOR(o) {
+        const float xc = x - cx, yc = y - cy, zc = z - cz;
+        const float dist = powf(xc, 2.0f) + powf(yc, 2.0f) + powf(zc, 2.0f);
+        if (dist < powf(radius, 2.0f)) o->s[IDX(o, x, y, z)] = CELL_OBJECT;
+    }
+}
+
+/* Source box in fractions of the resolution, density = 1 (Grid2::applySource,
+ * include/Grid2.h:55-61, with a z range added). */
+void o3_apply_source(O3 *o, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax) {
+    for (int z = (int)(zmin * o->nz); z < (int)(zmax * o->nz); z++)
+        for (int y = (int)(ymin * o->ny); y < (int)(ymax * o->ny); y++)
+            for (int x = (int)(xmin * o->nx); x < (int)(xmax * o->nx); x++) o->d[IDX(o, x, y, z)] = R(1.0);
+}
+
 /* main.cpp:60-74 */
 void o3_fill_sphere(O3 *o, float radius, float cx, float cy, float cz, int iter) {
     FOR_INTERIOR(o) {

@@ -42,6 +42,8 @@ def _lib(dtype):
     lib.o3_sphere_influence.argtypes = [P, C.c_float]
     lib.o3_fill_sphere.argtypes = [P] + [C.c_float] * 4 + [C.c_int]
     lib.o3_fill_sphere_influence.argtypes = [P, C.c_float, C.c_int]
+    lib.o3_solid_sphere.argtypes = [P] + [C.c_float] * 4
+    lib.o3_apply_source.argtypes = [P] + [C.c_double] * 6
     lib.o3_bottom_influence.argtypes = [P]
     lib.o3_clear.argtypes = [P]
     lib.o3_gs_lexi.restype = real
@@ -131,6 +133,12 @@ class Oracle3D:
 
     def fill_sphere(self, radius, cx, cy, cz, it):
         self.lib.o3_fill_sphere(self.h, radius, cx, cy, cz, it)
+
+    def solid_sphere(self, radius, cx, cy, cz):
+        self.lib.o3_solid_sphere(self.h, radius, cx, cy, cz)
+
+    def apply_source(self, xmin, xmax, ymin, ymax, zmin, zmax):
+        self.lib.o3_apply_source(self.h, xmin, xmax, ymin, ymax, zmin, zmax)
 
     def bottom_influence(self):
         self.lib.o3_bottom_influence(self.h)

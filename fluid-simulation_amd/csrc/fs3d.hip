@@ -55,6 +55,8 @@ struct Part {
 struct fs3d_sim {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;        // halo traffic of the one-pass sweep, overlapped with its interior
+    hipEvent_t ev_bnd = nullptr, ev_comm = nullptr;
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
     size_t esz = 4;
@@ -185,8 +187,9 @@ struct HaloOp {
     size_t elem = 1;
 };
 
-int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops) {
+int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st = nullptr) {
     if (s->nparts_global == 1) return FS_OK;
+    if (!st) st = s->stream;
     bool remote = false;
     for (Part& p : s->parts) {
         const size_t H = p.H;
@@ -199,9 +202,9 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops) {
                 Part& q = *(&p + 1);
                 char* theirs = (char*)op.base(s, q, op.which);
                 SIM_HIP(hipMemcpyAsync(theirs, mine + (size_t)p.own_planes() * plane, H * plane,
-                                       hipMemcpyDeviceToDevice, s->stream));
+                                       hipMemcpyDeviceToDevice, st));
                 SIM_HIP(hipMemcpyAsync(mine + (H + p.own_planes()) * plane, theirs + H * plane, H * plane,
-                                       hipMemcpyDeviceToDevice, s->stream));
+                                       hipMemcpyDeviceToDevice, st));
             }
         }
         if ((p.has_lo && &p == &s->parts.front()) || (p.has_hi && &p == &s->parts.back())) remote = true;
@@ -215,14 +218,14 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops) {
         if (lo.has_lo) {
             const size_t plane = (size_t)lo.g.sz * op.elem, H = lo.H;
             char* a = (char*)op.base(s, lo, op.which);
-            FS_TRY(nccl_check(s, R->Send(a + H * plane, H * plane, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclSend"));
-            FS_TRY(nccl_check(s, R->Recv(a, H * plane, ncclUint8, s->rank - 1, s->comm, s->stream), "ncclRecv"));
+            FS_TRY(nccl_check(s, R->Send(a + H * plane, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclRecv"));
         }
         if (hi.has_hi) {
             const size_t plane = (size_t)hi.g.sz * op.elem, H = hi.H;
             char* a = (char*)op.base(s, hi, op.which);
-            FS_TRY(nccl_check(s, R->Send(a + (size_t)hi.own_planes() * plane, H * plane, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclSend"));
-            FS_TRY(nccl_check(s, R->Recv(a + (H + hi.own_planes()) * plane, H * plane, ncclUint8, s->rank + 1, s->comm, s->stream), "ncclRecv"));
+            FS_TRY(nccl_check(s, R->Send(a + (size_t)hi.own_planes() * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a + (H + hi.own_planes()) * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclRecv"));
         }
     }
     return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
@@ -320,10 +323,69 @@ int launch_halfsweep(fs3d_sim* s, int colour) {
     return exchange_w_interfaces<T>(s, colour);
 }
 
-// One full red-black sweep in a single pass over HBM (fs_sweep_fused.hpp): reads the current
-// velocity generation, writes the other one, then the roles swap.  Slabs recompute the two ghost
-// planes below them (and one above) instead of exchanging per colour, and refresh their halos after
-// the sweep.
+// One full red-black sweep in a single pass over HBM: the kernels read the current velocity generation
+// and write the other one, then the roles swap.  `launch(part, z0, z1)` runs the kernel for the stored
+// plane range [z0, z1).  Slabs recompute the two ghost planes below them (and one above) instead of
+// exchanging per colour.  With more than one slab the two owned planes next to each interface are
+// produced first, their exchange runs on a second stream, and the interior of the slab is swept
+// meanwhile; the main stream picks the halos up before anything reads them.
+template <typename Launch>
+int one_pass_driver(fs3d_sim* s, Launch launch) {
+    if (s->nparts_global == 1) {
+        for (Part& p : s->parts) launch(p, 0, p.g.nzl);
+        SIM_HIP(hipGetLastError());
+        s->curv ^= 1;
+        return FS_OK;
+    }
+    struct Mid { int b, e; };
+    std::vector<Mid> mid;
+    for (Part& p : s->parts) {
+        const int own_lo = p.H, own_hi = p.H + p.own_planes();
+        const int lo_end = p.has_lo ? std::min(own_lo + 2, own_hi) : own_lo;
+        const int hi_beg = p.has_hi ? std::max(own_hi - 2, lo_end) : own_hi;
+        if (lo_end > own_lo) launch(p, own_lo, lo_end);
+        if (own_hi > hi_beg) launch(p, hi_beg, own_hi);
+        mid.push_back({lo_end, hi_beg});
+    }
+    SIM_HIP(hipGetLastError());
+    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));
+    for (size_t k = 0; k < s->parts.size(); ++k)
+        if (mid[k].e > mid[k].b) launch(s->parts[k], mid[k].b, mid[k].e);
+    SIM_HIP(hipGetLastError());
+    s->curv ^= 1;   // the halo operators below address the new generation
+    SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
+    std::vector<HaloOp> ops;
+    for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
+    FS_TRY(exchange_halos(s, ops, s->comm_stream));
+    SIM_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
+    SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    return FS_OK;
+}
+
+template <typename T>
+FusedRanges fused_ranges(const Part& p) {
+    FusedRanges r;
+    r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
+    r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
+    r.z0 = 0; r.z1 = 0; r.zchunk = 1;
+    return r;
+}
+
+// z-chunks of one launch: pick the chunk count that minimises (rounds of workgroups over the CUs) x
+// (planes a workgroup marches through, its overlap and pipeline planes included).
+inline int pick_chunks(int planes, int tiles, int slots) {
+    int best_c = 1;
+    double best = 1e300;
+    for (int c = 1; c <= std::max(1, planes / 8); ++c) {
+        const int zc = div_up(planes, c);
+        const int rounds = div_up(tiles * div_up(planes, zc), slots);
+        const double cost = (double)rounds * (zc + 7);
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    return best_c;
+}
+
+// The LDS-window form (fs_sweep_fused.hpp); any nx.
 template <typename T>
 int launch_fused_sweep(fs3d_sim* s) {
     constexpr int TX = 64, TY = 8;
@@ -332,29 +394,19 @@ int launch_fused_sweep(fs3d_sim* s) {
     SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
-    for (Part& p : s->parts) {
-        FusedRanges r;
-        r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
-        r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
-        const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
-        int nchunks = std::max(1, std::min(div_up(1024, tiles), p.g.nzl / 24));
-        r.zchunk = div_up(p.g.nzl, nchunks);
-        nchunks = div_up(p.g.nzl, r.zchunk);
-        dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), nchunks);
+    const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
+    return one_pass_driver(s, [&](Part& p, int z0, int z1) {
+        FusedRanges r = fused_ranges<T>(p);
+        r.z0 = z0; r.z1 = z1;
+        const int nchunks = pick_chunks(z1 - z0, tiles, 2 * s->num_cus);
+        r.zchunk = div_up(z1 - z0, nchunks);
+        dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), div_up(z1 - z0, r.zchunk));
         hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
                            F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r);
-    }
-    SIM_HIP(hipGetLastError());
-    s->curv = ov;
-    if (s->nparts_global > 1) {
-        std::vector<HaloOp> ops;
-        for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
-        FS_TRY(exchange_halos(s, ops));
-    }
-    return FS_OK;
+    });
 }
 
-// The register-resident form of the fused sweep (fs_sweep_rows.hpp); needs an even nx.
+// The register-resident form (fs_sweep_rows.hpp); needs an even nx.
 template <typename T, int NSEG>
 int launch_rows_sweep(fs3d_sim* s) {
     using C = RowsCfg<T, NSEG>;
@@ -364,34 +416,15 @@ int launch_rows_sweep(fs3d_sim* s) {
     const int cv = s->curv, ov = s->curv ^ 1;
     const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
     const int nty = s->ny <= C::RY ? 1 : div_up(s->ny - 4, C::RY - 4);
-    for (Part& p : s->parts) {
-        FusedRanges r;
-        r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
-        r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
-        // z-chunks: one workgroup is resident per CU; pick the chunk count that minimises
-        // (rounds of workgroups) x (planes a workgroup marches through, its 4 overlap planes included)
-        int nchunks = 1;
-        double best = 1e300;
-        for (int c = 1; c <= std::max(1, p.g.nzl / 8); ++c) {
-            const int zc = div_up(p.g.nzl, c);
-            const int rounds = div_up(ntx * nty * div_up(p.g.nzl, zc), s->num_cus);
-            const double cost = (double)rounds * (zc + 7);
-            if (cost < best) { best = cost; nchunks = c; }
-        }
-        r.zchunk = div_up(p.g.nzl, nchunks);
-        nchunks = div_up(p.g.nzl, r.zchunk);
-        dim3 b(64, C::RY, 1), g(ntx, nty, nchunks);
+    return one_pass_driver(s, [&](Part& p, int z0, int z1) {
+        FusedRanges r = fused_ranges<T>(p);
+        r.z0 = z0; r.z1 = z1;
+        const int nchunks = pick_chunks(z1 - z0, ntx * nty, s->num_cus);   // one workgroup per CU
+        r.zchunk = div_up(z1 - z0, nchunks);
+        dim3 b(64, C::RY, 1), g(ntx, nty, div_up(z1 - z0, r.zchunk));
         hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
                            F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty);
-    }
-    SIM_HIP(hipGetLastError());
-    s->curv = ov;
-    if (s->nparts_global > 1) {
-        std::vector<HaloOp> ops;
-        for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
-        FS_TRY(exchange_halos(s, ops));
-    }
-    return FS_OK;
+    });
 }
 
 template <typename T>
@@ -798,6 +831,9 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     if (s->num_cus < 1) s->num_cus = 256;
     SIM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) SIM_HIP(hipEventCreate(&e));
+    SIM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    SIM_HIP(hipEventCreateWithFlags(&s->ev_bnd, hipEventDisableTiming));
+    SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 2)));
     SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 2, hipHostMallocDefault));
     SIM_HIP(hipMalloc((void**)&s->doob, sizeof(int)));
@@ -929,6 +965,9 @@ void fs3d_destroy(fs3d_sim* s) {
     if (s->hres) (void)hipHostFree(s->hres);
     if (s->hoob) (void)hipHostFree(s->hoob);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->comm_stream) { (void)hipStreamSynchronize(s->comm_stream); (void)hipStreamDestroy(s->comm_stream); }
+    if (s->ev_bnd) (void)hipEventDestroy(s->ev_bnd);
+    if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

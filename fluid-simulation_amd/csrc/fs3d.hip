@@ -406,7 +406,10 @@ int launch_fused_sweep(fs3d_sim* s) {
     });
 }
 
-// The register-resident form (fs_sweep_rows.hpp); needs an even nx.
+// The register-resident form (fs_sweep_rows.hpp); needs an even nx.  Measured at 512^3: the time of a
+// launch follows the total number of (row, plane) steps, not the number of busy CUs, so the tile keeps
+// the most rows a workgroup can have (the smallest share of halo rows) and the z-chunking only has to
+// provide about one workgroup per CU.
 template <typename T, int NSEG>
 int launch_rows_sweep(fs3d_sim* s) {
     using C = RowsCfg<T, NSEG>;
@@ -414,16 +417,17 @@ int launch_rows_sweep(fs3d_sim* s) {
     SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
+    const int rows = std::min(C::RY, s->ny);
     const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
-    const int nty = s->ny <= C::RY ? 1 : div_up(s->ny - 4, C::RY - 4);
+    const int nty = s->ny <= rows ? 1 : div_up(s->ny - 4, rows - 4);
     return one_pass_driver(s, [&](Part& p, int z0, int z1) {
         FusedRanges r = fused_ranges<T>(p);
         r.z0 = z0; r.z1 = z1;
-        const int nchunks = pick_chunks(z1 - z0, ntx * nty, s->num_cus);   // one workgroup per CU
+        const int nchunks = pick_chunks(z1 - z0, ntx * nty, s->num_cus);
         r.zchunk = div_up(z1 - z0, nchunks);
-        dim3 b(64, C::RY, 1), g(ntx, nty, div_up(z1 - z0, r.zchunk));
+        dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
         hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
-                           F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty);
+                           F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty, rows);
     });
 }
 

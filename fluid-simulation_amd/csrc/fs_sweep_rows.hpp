@@ -1,7 +1,7 @@
 // One full red-black sweep in one pass over HBM, register-resident variant
 // for even nx (the arrays are then 8-byte aligned per column pair).
 //
-// A workgroup is RY = 16 waves; wave r owns row y0 + r of a tile that is
+// A workgroup is up to 16 waves; wave r owns row y0 + r of a tile that is
 // W = 128*NSEG columns wide, lane l owns the column pairs (2l, 2l+1) + 128*sg.
 // The wave marches along z.  For its two columns a lane keeps u and w of the
 // five planes in flight in registers: the two cells a w face touches lie in
@@ -37,7 +37,7 @@ struct RowPlane {            // what a lane holds of one z-plane
 
 template <typename T, int NSEG>
 struct RowsCfg {
-    static constexpr int RY = 16;
+    static constexpr int RY = 16;           // most rows (waves) a workgroup can have
     static constexpr int W = 128 * NSEG;
     static constexpr int NPV = 3;   // v planes in LDS
     static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
@@ -47,23 +47,30 @@ template <typename T, int NSEG>
 __global__ void __launch_bounds__(1024)
 k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
-          FusedRanges r, int ntx, int nty) {
+          FusedRanges r, int ntx, int nty, int rows) {
     using C = RowsCfg<T, NSEG>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][RY][W], rows de-interleaved: even columns, then odd
 
     const int lane = threadIdx.x, ry = threadIdx.y;
-    const int bx = blockIdx.x, by = blockIdx.y;
-    const int xr0 = bx * (C::W - 4), yr0 = by * (C::RY - 4);   // tile origin; tiles overlap by 4
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Renumber them so that the
+    // workgroups sharing an XCD are y-neighbours of one z-chunk: the two halo rows a tile shares with each
+    // neighbour are then fetched from HBM once and served from that L2 the second time.  (Placement is a
+    // speed matter only; any mapping gives the same result.)
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int xcd = lin & 7, q = total >> 3, rem = total & 7;
+    const int logical = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+    const int by = logical % nty, bx = (logical / nty) % ntx, bz = logical / (nty * ntx);
+    const int xr0 = bx * (C::W - 4), yr0 = by * (rows - 4);   // tile origin; tiles overlap by 4
     const int y = yr0 + ry;
     const bool row_in = y < g.ny;
     // the part of the tile this workgroup stores: everything but the two stale rings, except at the
     // domain boundary where there is no neighbour tile
     const int cx_lo = bx == 0 ? 0 : xr0 + 2, cx_hi = bx == ntx - 1 ? g.nx : xr0 + C::W - 2;
-    const int cy_lo = by == 0 ? 0 : yr0 + 2, cy_hi = by == nty - 1 ? g.ny : yr0 + C::RY - 2;
+    const int cy_lo = by == 0 ? 0 : yr0 + 2, cy_hi = by == nty - 1 ? g.ny : yr0 + rows - 2;
     const bool row_core = y >= cy_lo && y < cy_hi;
 
-    const int c0 = r.z0 + blockIdx.z * r.zchunk, c1 = min(c0 + r.zchunk, r.z1);
+    const int c0 = r.z0 + bz * r.zchunk, c1 = min(c0 + r.zchunk, r.z1);
     const int s1b = max(r.s1b, c0 - 1), s1e = min(r.s1e, c1);
     const int s0b = max(r.s0b, c0 - 2), s0e = min(r.s0e, c1 + 1);
     const int lb = max(0, c0 - 2), le = min(g.nzl, c1 + 2);
@@ -107,7 +114,7 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
             X.w[sg][0] = pw.a; X.w[sg][1] = pw.b;
         }
     };
-    auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 3 * C::NPV) % C::NPV) * C::RY + row) * C::W; };
+    auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 3 * C::NPV) % C::NPV) * rows + row) * C::W; };
     auto stage_v = [&](int p) {   // v staging registers -> LDS, own row
         T* row = vrow(p, ry);
 #pragma unroll
@@ -120,8 +127,8 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     auto relax = [&](RowPlane<T, NSEG>& X, RowPlane<T, NSEG>& Y, int p, int colour) {
         const int c = (colour + xr0 + y + p + g.gz0) & 1;   // the active column of every pair of this row
         T* v0row = vrow(p, ry);
-        T* v1row = vrow(p, ry < C::RY - 1 ? ry + 1 : ry);
-        const bool row_ok = ry < C::RY - 1;
+        T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
+        const bool row_ok = ry < rows - 1;
         T send[NSEG];
         if (c == 0) {
 #pragma unroll

@@ -7,7 +7,8 @@
 A "step" is one full fs3d_advance(): (buoyancy off) projection, half advection, projection,
 reflection, half advection of the synthetic vortex-ring scene, with the projection run to the L2
 residual of 3_fluid/FluidSim.cpp:17-43 <= 1e-6 or the reference's cap of 1000 sweeps
-(advection-reflection/main.cpp:108), checked every 8th sweep.
+(advection-reflection/main.cpp:108); the residual is evaluated from one sweep before the count the
+previous step needed and then after every sweep (the reference evaluates it after every sweep).
 
 Workloads (BASELINE.json configs):
   N = 1   "Vortex ring 256^3 on one MI355X, GS to residual 1e-6, fp32"        (configs[1])
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--max-iters", type=int, default=1000)
-    ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--check-every", type=int, default=0, help="0 = adaptive schedule")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--step-mode", type=int, default=1, help="0 reference step, 1 advection-reflection")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f32 = the reference's precision")
@@ -171,7 +172,9 @@ def main():
             "config": {
                 "workload": f"{a.scene.replace('_', ' ')} {nx}x{ny}x{nz}, dt 1/30, "
                             f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}, "
-                            f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, checked every {a.check_every}",
+                            f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, "
+                            + ("residual evaluated from one sweep before the previous step's count, then every sweep"
+                               if a.check_every == 0 else f"checked every {a.check_every}"),
                 "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}",
                 "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
                 "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,

@@ -73,6 +73,7 @@ struct fs3d_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     fs3d_stats stats{};
     int num_cus = 256;
+    int sweep_hint[2] = {1, 1};  // sweeps the first / second projection of the previous step needed
     double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
     std::string err;
 };
@@ -545,15 +546,22 @@ int sweep_with_change(fs3d_sim* s, double* change) {
 }
 
 // The loop of update() (main.cpp:105-111) under the configured stopping rule.
+// check_every == 0 selects the adaptive schedule: the metric is first evaluated one sweep before the
+// count the same projection of the previous step needed, then after every sweep (consecutive steps need
+// nearly the same number of sweeps, so this costs one or two evaluations and stops at the exact sweep).
 template <typename T>
-int project(fs3d_sim* s, int* sweeps_out, double* metric_out) {
+int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
     FS_TRY(prepare(s));
     const fs3d_config& c = s->cfg;
+    const bool adaptive = c.check_every == 0;
     const int every = std::max(1, c.check_every);
+    const int first = adaptive ? std::max(1, s->sweep_hint[slot & 1] - 1) : 1;
+    const int coarse = std::max(8, first / 4);   // sparse early checks, so that a stale hint cannot cost much
     int it = 0;
     double metric = 0;
     for (;;) {
-        const bool check = ((it + 1) % every == 0) || (it + 1 >= c.max_iters);
+        const bool check = (adaptive ? (it + 1 >= first || (it + 1) % coarse == 0) : ((it + 1) % every == 0)) ||
+                           (it + 1 >= c.max_iters);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
             FS_TRY(sweep_with_change<T>(s, &metric));
         } else {
@@ -568,6 +576,8 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out) {
         }
         if (it >= c.max_iters) break;
     }
+    // a projection that ran into the cap says nothing about the next one: start checking at once
+    s->sweep_hint[slot & 1] = (it >= c.max_iters && metric > c.tol) ? 1 : it;
     s->stats.sweeps = it;
     s->stats.sweeps_step += it;
     s->stats.metric = metric;
@@ -648,7 +658,7 @@ int step(fs3d_sim* s, double dt) {
         for (Part& p : s->parts)
             for (int k = 0; k < 3; ++k)
                 SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->curv][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
-        FS_TRY(project<T>(s, nullptr, nullptr));
+        FS_TRY(project<T>(s, nullptr, nullptr, 1));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
         for (Part& p : s->parts)
             hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
@@ -804,7 +814,7 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->stop_mode < FS_STOP_FIXED || c->stop_mode > FS_STOP_L2_RESIDUAL) { *why = "bad stop_mode"; return false; }
     if (c->step_mode != FS_STEP_REFERENCE && c->step_mode != FS_STEP_REFLECTION) { *why = "bad step_mode"; return false; }
     if (c->max_iters < 1) { *why = "max_iters must be >= 1"; return false; }
-    if (c->check_every < 1) { *why = "check_every must be >= 1"; return false; }
+    if (c->check_every < 0) { *why = "check_every must be >= 0"; return false; }
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
@@ -982,6 +992,7 @@ int fs3d_reset(fs3d_sim* s) {
     FS_TRY(init_cells(s));
     s->curv = 0;
     s->curd = 0;
+    s->sweep_hint[0] = s->sweep_hint[1] = 1;
     s->stats = fs3d_stats{};
     s->halo_dirty = true;
     SIM_HIP(hipStreamSynchronize(s->stream));

@@ -87,7 +87,8 @@ typedef struct fs3d_config {
     int32_t ordering;     /* FS_ORDER_*                                                           */
     int32_t stop_mode;    /* FS_STOP_*                                                            */
     int32_t max_iters;    /* sweep cap; the reference uses 1000 (main.cpp:108)                    */
-    int32_t check_every;  /* evaluate the stopping metric every n-th sweep (>= 1)                 */
+    int32_t check_every;  /* evaluate the stopping metric every n-th sweep; 0 = adaptive: first one
+                             sweep before the count the previous step needed, then every sweep      */
     int32_t step_mode;    /* FS_STEP_*                                                            */
     int32_t local_slabs;  /* >= 1: cut this handle's planes into that many z-slabs on its own GPU
                              (exercises the multi-GPU slab path inside one process)            */

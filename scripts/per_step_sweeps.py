@@ -1,0 +1,22 @@
+"""Print the sweep count of every step for several check schedules (GPU)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fsamd_loader
+fs = fsamd_loader.load()
+import fluid_simulation_amd.scenes as scenes
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+for ce in (1, 0, 8):
+    sim = fs.FluidSim3D(n, n, n, stop_mode=fs.STOP_L2_RESIDUAL, tol=1e-6, max_iters=1000,
+                        check_every=ce, step_mode=1)
+    init, per_step = scenes.SCENES["vortex_ring"]
+    init(sim)
+    out = []
+    for it in range(steps):
+        per_step(sim, it)
+        sim.advance(1.0 / 30.0)
+        out.append(sim.stats().sweeps_step)
+    sim.synchronize()
+    print("check_every", ce, out, flush=True)
+    sim.close()

@@ -25,6 +25,7 @@
 #include "fs_kernels3d.hpp"
 #include "fs_sweep_fused.hpp"
 #include "fs_sweep_rows.hpp"
+#include "fs_advect_tiled.hpp"
 
 using namespace fsamd;
 
@@ -590,31 +591,63 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
 // ---- advection / reflection ------------------------------------------------
 // Carries q = (qu,qv,qw from `qsrc`, density of the current generation) along the current
 // generation's velocity into the other generation, then swaps generations.
+template <typename T, typename OFF, bool SLAB>
+int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, int cv, int ov, int cd, int od, T t_step,
+                  int density_mode, bool copy_to_tmp) {
+    // the owned planes, shell included, so that the new generation is complete
+    const int zb = p.H, ze = p.H + p.own_planes();
+    T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
+    T* c1 = copy_to_tmp ? (T*)p.tmp[1] : nullptr;
+    T* c2 = copy_to_tmp ? (T*)p.tmp[2] : nullptr;
+    const T *U = F<T>(p, cv, 0), *V = F<T>(p, cv, 1), *W = F<T>(p, cv, 2);
+    if (s->cfg.advect_kernel == FS_ADVECT_DIRECT) {
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
+        hipLaunchKernelGGL((k_advect<T, OFF, SLAB>), g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0),
+                           F<T>(p, ov, 1), F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb,
+                           s->doob);
+        return FS_OK;
+    }
+    auto go = [&](auto kern, size_t lds) -> int {
+        SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int tiles = div_up(s->nx, 64) * div_up(s->ny, 8);
+        const int nchunks = pick_chunks(ze - zb, tiles, 2 * s->num_cus);
+        const int zchunk = div_up(ze - zb, nchunks);
+        dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), div_up(ze - zb, zchunk));
+        hipLaunchKernelGGL(kern, g, b, lds, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0), F<T>(p, ov, 1),
+                           F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob);
+        return FS_OK;
+    };
+    if (qu == U) return go(k_advect_tiled<T, OFF, false, SLAB>, AdvTile<T, false>::lds_bytes());
+    return go(k_advect_tiled<T, OFF, true, SLAB>, AdvTile<T, true>::lds_bytes());
+}
+
+// copy_to_tmp: the new velocity is also written to the scratch fields (the unprojected half-step
+// field the reflection needs later).
 template <typename T>
-int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode) {
+int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false) {
     FS_TRY(prepare(s));
     if (s->nparts_global > 1) {
         FS_TRY(exchange_state_halos(s));
         if (q_from_tmp) FS_TRY(exchange_halos(s, {{base_tmp, 0, s->esz}, {base_tmp, 1, s->esz}, {base_tmp, 2, s->esz}}));
     }
-    SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
+    const bool slab = s->nparts_global > 1;
+    if (slab) SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
     for (Part& p : s->parts) {
-        // the owned planes, shell included, so that the new generation is complete
-        const int zb = p.H, ze = p.H + p.own_planes();
-        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
         const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
         const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
         const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
-        hipLaunchKernelGGL(k_advect<T>, g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), F<T>(p, cv, 0), F<T>(p, cv, 1),
-                           F<T>(p, cv, 2), F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), F<T>(p, od, 3), p.flags, (T)t_step,
-                           density_mode, zb, ze, s->doob);
+        const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
+        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
+        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
+        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
+        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
     }
     SIM_HIP(hipGetLastError());
     s->curv = ov;
     s->curd = od;
     s->halo_dirty = s->nparts_global > 1;
-    if (s->nparts_global > 1) {   // a backtrace beyond the halo cannot be served: report it
+    if (slab) {   // a backtrace beyond the halo cannot be served: report it
         SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         SIM_HIP(hipStreamSynchronize(s->stream));
         if (*s->hoob) return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells)");
@@ -654,10 +687,7 @@ int step(fs3d_sim* s, double dt) {
         // leaving the advected field for the next step to project:
         //   u0 = P(state); ut = A(u0; u0, dt/2); uh = P(ut); ur = 2 uh - ut; state = A(ur; uh, dt/2)
         FS_TRY(project<T>(s, nullptr, nullptr));
-        FS_TRY(advect<T>(s, 0.5 * dt, false, 0));
-        for (Part& p : s->parts)
-            for (int k = 0; k < 3; ++k)
-                SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->curv][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+        FS_TRY(advect<T>(s, 0.5 * dt, false, 0, true));   // ut goes to the scratch fields as well
         FS_TRY(project<T>(s, nullptr, nullptr, 1));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
         for (Part& p : s->parts)
@@ -817,6 +847,7 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->check_every < 0) { *why = "check_every must be >= 0"; return false; }
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
+    if (c->advect_kernel < FS_ADVECT_TILED || c->advect_kernel > FS_ADVECT_DIRECT) { *why = "bad advect_kernel"; return false; }
     if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
     return true;
 }
@@ -888,6 +919,7 @@ void fs3d_default_config(fs3d_config* c) {
     c->step_mode = FS_STEP_REFERENCE;
     c->local_slabs = 1;
     c->sweep_kernel = FS_SWEEP_FUSED;
+    c->advect_kernel = FS_ADVECT_TILED;
     c->tol = 5.0;
     c->omega = 1.0;
     c->buoyancy = 0.0;

@@ -1,0 +1,173 @@
+// Semi-Lagrangian advection with the fields staged through LDS.
+//
+// The direct kernel (k_advect) issues about 32 gather loads per cell and keeps
+// the texture-address unit of every CU busy ~90 % of the time; it is bound by
+// load issue, not by HBM.  Here a workgroup of 64 x 8 threads marches its
+// column of cells along z with a ring of four planes of every field in LDS
+// (the plane being computed, one plane either side, one plane in flight), each
+// plane widened by a one-cell apron in x and y.  Every global element is then
+// loaded once per workgroup with coalesced row loads (1.3 loads per cell and
+// field), and the 13-point velocity neighbourhood and the eight taps of each
+// of the four samples (advection-reflection/main.cpp:256-291, :380-435) are
+// LDS reads.
+//
+// A backtrace that ends inside the window (|v| dt < 1 cell, the usual case) is
+// served from LDS; any other sample takes the global loads of the direct
+// kernel, lane by lane, so the result does not depend on the window size.  The
+// arithmetic is that of k_advect, bit for bit.
+#pragma once
+#include "fs_kernels3d.hpp"
+
+namespace fsamd {
+
+template <typename T, bool SEP>
+struct AdvTile {
+    static constexpr int TX = 64, TY = 8, R = 1, NPL = 4;   // NPL = 2R+2 planes, a power of two
+    static constexpr int WX = TX + 2 * R, WY = TY + 2 * R, PS = WX * WY;
+    static constexpr int NF = SEP ? 7 : 4;                  // u,v,w,d carried (+ the carrying velocity if it is another field)
+    static constexpr int NT = TX * TY;
+    static constexpr int NLD = (PS + NT - 1) / NT;
+    static constexpr size_t lds_bytes() { return (size_t)NF * NPL * PS * sizeof(T); }
+};
+
+// SEP: the carrying velocity (U,V,W) is not (qu,qv,qw).  SLAB: the arrays hold only some planes of the grid.
+template <typename T, typename OFF, bool SEP, bool SLAB>
+__global__ void __launch_bounds__(512)
+k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
+               const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
+               T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od, T* __restrict__ cu,
+               T* __restrict__ cv, T* __restrict__ cw, const uint8_t* __restrict__ flags, T t_step, int density_mode,
+               int zb, int ze, int zchunk, int* __restrict__ oob_flag) {
+    using C = AdvTile<T, SEP>;
+    constexpr int R = C::R, WX = C::WX, PS = C::PS, NPL = C::NPL;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* L = reinterpret_cast<T*>(lds_raw);   // [field][ring slot][WY][WX]
+
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * C::TX + tx;
+    const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY;
+    const int c0 = zb + blockIdx.z * zchunk, c1 = min(c0 + zchunk, ze);
+    const OFF sy = (OFF)g.nx * (OFF)sizeof(T), sz = (OFF)g.nx * (OFF)g.ny * (OFF)sizeof(T);
+    const T* src[7] = {qu, qv, qw, qd, U, V, W};
+
+    // the window elements this thread stages (the same for every plane).  Elements outside the grid are
+    // never the tap of a sample (tap addresses are clamped into the grid): they are loaded from a clamped,
+    // valid address so that no load needs a branch.
+    static_assert(C::NLD == 2, "a thread stages two elements per plane and field");
+    OFF soff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = min(tid + k * C::NT, PS - 1);
+        const int ry = e / WX, rx = e - ry * WX;
+        const int gx = min(max(x0 - R + rx, 0), g.nx - 1), gy = min(max(y0 - R + ry, 0), g.ny - 1);
+        soff[k] = ((OFF)gy * (OFF)g.nx + (OFF)gx) * (OFF)sizeof(T);
+    }
+    const bool second = tid + C::NT < PS;   // this thread has a second element
+    T stage[C::NF][2];
+    auto fetch = [&](int p) {    // global -> registers
+        const OFF po = (OFF)min(max(p, 0), g.nzl - 1) * sz;
+#pragma unroll
+        for (int f = 0; f < C::NF; ++f) stage[f][0] = *at_byte(src[f], po + soff[0]);
+        if (second) {
+#pragma unroll
+            for (int f = 0; f < C::NF; ++f) stage[f][1] = *at_byte(src[f], po + soff[1]);
+        }
+    };
+    auto commit = [&](int p) {   // registers -> LDS
+        T* dst = L + (p & (NPL - 1)) * PS + tid;
+#pragma unroll
+        for (int f = 0; f < C::NF; ++f) dst[f * NPL * PS] = stage[f][0];
+        if (second) {
+#pragma unroll
+            for (int f = 0; f < C::NF; ++f) dst[f * NPL * PS + C::NT] = stage[f][1];
+        }
+    };
+    auto plane = [&](int f, int p) -> const T* { return L + (f * NPL + (p & (NPL - 1))) * PS; };
+
+    const int x = x0 + tx, y = y0 + ty;
+    const bool mine = x < g.nx && y < g.ny;
+    const int wl = (ty + R) * WX + tx + R;   // own cell inside the window
+    constexpr int VF = SEP ? 4 : 0;          // first field of the carrying velocity
+
+    // A sample.  The eight LDS reads are unconditional (from the own cell when the backtrace left the
+    // window) so that the reads of all samples of a cell are in flight together; a sample outside the
+    // window then replaces them by global loads.
+    auto sample = [&](int f, const FastTrace<T, OFF>& tr, int z) -> T {
+        Taps<T> t;
+        const uint32_t ax = (uint32_t)(tr.cx - (x0 - R)), ay = (uint32_t)(tr.cy - (y0 - R)), az = (uint32_t)(tr.cz - (z - R));
+        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
+        const int a = in ? (int)ay * WX + (int)ax : wl;
+        const int pz = in ? tr.cz : z;
+        const T* p0 = L + (f * NPL + (pz & (NPL - 1))) * PS + a;
+        const T* p1 = L + (f * NPL + ((pz + 1) & (NPL - 1))) * PS + a;
+        t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[WX]; t.s[3] = p1[0];
+        t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
+        if (__builtin_expect(!in, 0)) {
+            // volatile: keeps these loads apart from the LDS reads above (merged, the pair becomes one
+            // generic-address load per tap, which is served at a fraction of the LDS rate)
+            const volatile T* r00 = at_byte(src[f], trace_base(g, tr));
+            const volatile T* r10 = at_byte(src[f], trace_base(g, tr) + sy);
+            const volatile T* r01 = at_byte(src[f], trace_base(g, tr) + sz);
+            const volatile T* r11 = at_byte(src[f], trace_base(g, tr) + sz + sy);
+            t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
+            t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
+        }
+        return fast_finish(tr, t);
+    };
+
+    auto compute = [&](int z) {
+        const int gz = z + g.gz0;
+        const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
+        const OFF i = e * (OFF)sizeof(T);
+        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
+        const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
+        if (interior) {
+            const uint32_t fl = flags[e];
+            const T four = (T)4, two = (T)2;
+            const bool fluid = fl & FL_SELF_FLUID;
+            const T* Uc = plane(VF + 0, z) + wl; const T* Uzm = plane(VF + 0, z - 1) + wl;
+            const T* Vc = plane(VF + 1, z) + wl; const T* Vzm = plane(VF + 1, z - 1) + wl;
+            const T* Wc = plane(VF + 2, z) + wl; const T* Wzp = plane(VF + 2, z + 1) + wl;
+            const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uc[-WX], u_xp_ym = Uc[1 - WX], u_zm = Uzm[0], u_xp_zm = Uzm[1];
+            const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vc[WX], v_xm_yp = Vc[WX - 1], v_zm = Vzm[0], v_yp_zm = Vzm[WX];
+            const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wc[-WX], w_ym_zp = Wzp[-WX];
+            // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
+            const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
+            const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
+            const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
+            const FastTrace<T, OFF> tu = fast_prepare<T, OFF, SLAB>(g, x, y, gz, u_c, uy, uz, t_step);
+            const FastTrace<T, OFF> tv = fast_prepare<T, OFF, SLAB>(g, x, y, gz, vx, v_c, vz, t_step);
+            const FastTrace<T, OFF> tw = fast_prepare<T, OFF, SLAB>(g, x, y, gz, wx, wy, w_c, t_step);
+            bool oob = fluid && (tu.oob || tv.oob || tw.oob);
+            const T su = sample(0, tu, z), sv = sample(1, tv, z), sw = sample(2, tw, z);
+            if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
+            // main.cpp:284-289
+            T uc, vc, wc;
+            if (density_mode == 1) {
+                uc = (nu + u_xp) / two; vc = (nv + v_yp) / two; wc = (nw + w_zp) / two;
+            } else {
+                uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
+            }
+            const FastTrace<T, OFF> td = fast_prepare<T, OFF, SLAB>(g, x, y, gz, uc, vc, wc, t_step);
+            const T sd = sample(3, td, z);
+            if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || td.oob; }
+            if (SLAB && oob) *oob_flag = 1;
+        }
+        *const_cast<T*>(at_byte<T, OFF>(ou, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(ov, i)) = nv;
+        *const_cast<T*>(at_byte<T, OFF>(ow, i)) = nw; *const_cast<T*>(at_byte<T, OFF>(od, i)) = nd;
+        if (cu) {
+            *const_cast<T*>(at_byte<T, OFF>(cu, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(cv, i)) = nv;
+            *const_cast<T*>(at_byte<T, OFF>(cw, i)) = nw;
+        }
+    };
+
+    for (int p = c0 - R; p <= c0 + R; ++p) { fetch(p); commit(p); }
+    __syncthreads();
+    for (int z = c0; z < c1; ++z) {
+        fetch(z + R + 1);
+        if (mine) compute(z);
+        commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
+        __syncthreads();
+    }
+}
+
+}  // namespace fsamd

@@ -348,47 +348,166 @@ __device__ __forceinline__ T trace_combine(const Trace<T>& tr, const Taps<T>& t)
     return r;
 }
 
+// ---- the same sampler, arranged for the vector ALU ---------------------------
+// The advection kernel is bound by vector-ALU issue, not by memory, so the
+// common case is kept short.  Instead of masking each of the eight taps, the
+// three per-axis weight pairs are zeroed where the reference would not read the
+// tap: a zero factor makes the tap's term an exact zero, which leaves the sum
+// unchanged.  The test for non-finite taps is made once, on the result: a
+// non-finite tap, wanted or not, always makes the raw sum non-finite, and only
+// then are the taps cleaned one by one and combined again.  A backtrace that
+// ends beyond 2^23 cells (where the reference's (n-b)/(t-b) of main.cpp:391-393
+// stops being n-b) reads no tap at all; it keeps the reference's weights, NaN
+// included, and takes the same second combine with every tap zero.  The weights
+// are the same products in the same order, so the result has the bits of the
+// masked form in every case.
+//
+// OFF is the type of a byte offset into a field: uint32_t when the arrays are
+// smaller than 4 GiB (one address add per tap row instead of 64-bit arithmetic).
+template <typename T, typename OFF>
+struct FastTrace {
+    T x0, x1, y0, y1, z0, z1;   // (1-fu), fu, (1-fv), fv, (1-fw), fw, or 0 where the tap is not read
+    int cx, cy, cz;             // tap 0, clamped into the array (cz is a local plane)
+    bool oob, far;
+};
+
+template <typename T, typename OFF>
+__device__ __forceinline__ OFF trace_base(const Grid& g, const FastTrace<T, OFF>& tr) {   // byte offset of tap 0
+    return (((OFF)tr.cz * (OFF)g.ny + (OFF)tr.cy) * (OFF)g.nx + (OFF)tr.cx) * (OFF)sizeof(T);
+}
+
+template <typename T, typename OFF>
+__device__ __forceinline__ const T* at_byte(const T* __restrict__ q, OFF off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(q) + off);
+}
+
+template <typename T, typename OFF, bool SLAB>
+__device__ __forceinline__ FastTrace<T, OFF> fast_prepare(const Grid& g, int x, int y, int gz, T dx, T dy, T dz, T t_step) {
+    FastTrace<T, OFF> tr;
+    const T px = (T)x - dx * t_step;
+    const T py = (T)y - dy * t_step;
+    const T pz = (T)gz - dz * t_step;
+    const T bx = floor(px), by = floor(py), bz = floor(pz);
+    T fu = px - bx, fv = py - by, fw = pz - bz;
+    const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
+    const uint32_t mx = (uint32_t)(g.nx - 2), my = (uint32_t)(g.ny - 2), mz = (uint32_t)(g.gnz - 2);
+    // tap b is read when 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3
+    const bool x0 = (uint32_t)ibx - 1u < mx, x1 = (uint32_t)ibx < mx;
+    const bool y0 = (uint32_t)iby - 1u < my, y1 = (uint32_t)iby < my;
+    bool z0 = (uint32_t)ibz - 1u < mz, z1 = (uint32_t)ibz < mz;
+    const int lzb = ibz - g.gz0;
+    tr.oob = false;
+    if (SLAB) {   // planes of the global grid this slab does not hold
+        const bool h0 = (uint32_t)lzb < (uint32_t)g.nzl, h1 = (uint32_t)lzb + 1u < (uint32_t)g.nzl;
+        tr.oob = ((z0 && !h0) || (z1 && !h1)) && (x0 || x1) && (y0 || y1);
+        z0 = z0 && h0; z1 = z1 && h1;
+    }
+    const T one = (T)1, zero = (T)0;
+    tr.x0 = x0 ? one - fu : zero; tr.x1 = x1 ? fu : zero;
+    tr.y0 = y0 ? one - fv : zero; tr.y1 = y1 ? fv : zero;
+    tr.z0 = z0 ? one - fw : zero; tr.z1 = z1 ? fw : zero;
+    tr.far = !(fmax(fmax(fabs(bx), fabs(by)), fabs(bz)) < (T)8388608);
+    if (__builtin_expect(tr.far, 0)) {
+        fu = fu / ((bx + one) - bx); fv = fv / ((by + one) - by); fw = fw / ((bz + one) - bz);
+        tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
+    }
+    tr.cx = min(max(ibx, 0), g.nx - 2); tr.cy = min(max(iby, 0), g.ny - 2); tr.cz = min(max(lzb, 0), g.nzl - 2);
+    return tr;
+}
+
+template <typename T, typename OFF>
+__device__ __forceinline__ T fast_combine(const FastTrace<T, OFF>& tr, const Taps<T>& t) {
+    const T a00 = tr.x0 * tr.y0, a10 = tr.x1 * tr.y0, a01 = tr.x0 * tr.y1, a11 = tr.x1 * tr.y1;
+    T r = 0;
+    r += t.s[0] * (a00 * tr.z0);
+    r += t.s[1] * (a10 * tr.z0);
+    r += t.s[2] * (a01 * tr.z0);
+    r += t.s[3] * (a00 * tr.z1);
+    r += t.s[4] * (a11 * tr.z0);
+    r += t.s[5] * (a10 * tr.z1);
+    r += t.s[6] * (a01 * tr.z1);
+    r += t.s[7] * (a11 * tr.z1);
+    return r;
+}
+
+template <typename T, typename OFF>
+__device__ __forceinline__ Taps<T> fast_gather(const T* __restrict__ q, OFF base, OFF sy, OFF sz) {
+    const T* r00 = at_byte(q, base);
+    const T* r10 = at_byte(q, base + sy);
+    const T* r01 = at_byte(q, base + sz);
+    const T* r11 = at_byte(q, base + sz + sy);
+    Taps<T> t;
+    t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
+    t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
+    return t;
+}
+
+// combine, with the second combine for the rare cases
+template <typename T, typename OFF>
+__device__ __forceinline__ T fast_finish(const FastTrace<T, OFF>& tr, Taps<T>& t) {
+    T r = fast_combine(tr, t);
+    if (__builtin_expect(tr.far || !isfinite(r), 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t.s[k] = (tr.far || !isfinite(t.s[k])) ? (T)0 : t.s[k];
+        r = fast_combine(tr, t);
+    }
+    return r;
+}
+
+template <typename T, typename OFF>
+__device__ __forceinline__ T fast_sample(const Grid& g, const T* __restrict__ q, const FastTrace<T, OFF>& tr, OFF sy, OFF sz) {
+    Taps<T> t = fast_gather<T, OFF>(q, trace_base(g, tr), sy, sz);
+    return fast_finish(tr, t);
+}
+
 // One thread per location of planes [zb, ze): carries (qu,qv,qw,qd) along the
 // velocity (U,V,W) into (ou,ov,ow,od).  Locations the reference does not
 // advect (non-Fluid faces, Object densities, the shell) copy q.  density_mode 1
 // is the reference's cell-centre velocity: the cell's own, already advected
 // low faces averaged with the not yet advected high faces (main.cpp:285-287 in
 // serial order); density_mode 0 averages the carrying velocity's faces.
-template <typename T>
+// (cu,cv,cw), when given, receive a second copy of the new velocity.
+// SLAB says that the arrays hold only some planes of the grid.
+template <typename T, typename OFF, bool SLAB>
 __global__ void __launch_bounds__(256)
 k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
          const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
-         T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od,
-         const uint8_t* __restrict__ flags, T t_step, int density_mode, int zb, int ze, int* __restrict__ oob_flag) {
+         T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od, T* __restrict__ cu,
+         T* __restrict__ cv, T* __restrict__ cw, const uint8_t* __restrict__ flags, T t_step, int density_mode, int zb,
+         int* __restrict__ oob_flag) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z + zb;
     if (x >= g.nx || y >= g.ny) return;
-    const int64_t i = gidx(g, x, y, z);
+    const OFF sy = (OFF)g.nx * (OFF)sizeof(T), sz = (OFF)g.nx * (OFF)g.ny * (OFF)sizeof(T);
+    const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;   // element index
+    const OFF i = e * (OFF)sizeof(T);                                   // its byte offset
     const int gz = z + g.gz0;
-    T nu = qu[i], nv = qv[i], nw = qw[i], nd = qd[i];
+    T nu = *at_byte(qu, i), nv = *at_byte(qv, i), nw = *at_byte(qw, i), nd = *at_byte(qd, i);
     const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
     if (interior) {
-        const uint32_t fl = flags[i];
+        const uint32_t fl = flags[e];
         const T four = (T)4, two = (T)2;
         const bool fluid = fl & FL_SELF_FLUID;
-        // the 13-point neighbourhood of the carrying velocity
-        const T u_c = U[i], u_xp = U[i + 1], u_ym = U[i - g.sy], u_xp_ym = U[i + 1 - g.sy], u_zm = U[i - g.sz],
-                u_xp_zm = U[i + 1 - g.sz];
-        const T v_c = V[i], v_xm = V[i - 1], v_yp = V[i + g.sy], v_xm_yp = V[i - 1 + g.sy], v_zm = V[i - g.sz],
-                v_yp_zm = V[i + g.sy - g.sz];
-        const T w_c = W[i], w_xm = W[i - 1], w_zp = W[i + g.sz], w_xm_zp = W[i - 1 + g.sz], w_ym = W[i - g.sy],
-                w_ym_zp = W[i - g.sy + g.sz];
+        // the 13-point neighbourhood of the carrying velocity, by rows
+        const T* Uc = at_byte(U, i); const T* Uym = at_byte(U, i - sy); const T* Uzm = at_byte(U, i - sz);
+        const T* Vc = at_byte(V, i); const T* Vyp = at_byte(V, i + sy); const T* Vzm = at_byte(V, i - sz);
+        const T* Vypzm = at_byte(V, i + sy - sz);
+        const T* Wc = at_byte(W, i); const T* Wzp = at_byte(W, i + sz); const T* Wym = at_byte(W, i - sy);
+        const T* Wymzp = at_byte(W, i - sy + sz);
+        const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uym[0], u_xp_ym = Uym[1], u_zm = Uzm[0], u_xp_zm = Uzm[1];
+        const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vyp[0], v_xm_yp = Vyp[-1], v_zm = Vzm[0], v_yp_zm = Vypzm[0];
+        const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wym[0], w_ym_zp = Wymzp[0];
         // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
-        const Trace<T> tu = trace_prepare(g, x, y, gz, u_c, (v_c + v_xm + v_yp + v_xm_yp) / four,
-                                          (w_c + w_xm + w_zp + w_xm_zp) / four, t_step);
-        const Trace<T> tv = trace_prepare(g, x, y, gz, (u_c + u_ym + u_xp + u_xp_ym) / four, v_c,
-                                          (w_c + w_ym + w_zp + w_ym_zp) / four, t_step);
-        const Trace<T> tw = trace_prepare(g, x, y, gz, (u_c + u_zm + u_xp + u_xp_zm) / four,
-                                          (v_c + v_zm + v_yp + v_yp_zm) / four, w_c, t_step);
+        const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
+        const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
+        const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
+        const FastTrace<T, OFF> tu = fast_prepare<T, OFF, SLAB>(g, x, y, gz, u_c, uy, uz, t_step);
+        const FastTrace<T, OFF> tv = fast_prepare<T, OFF, SLAB>(g, x, y, gz, vx, v_c, vz, t_step);
+        const FastTrace<T, OFF> tw = fast_prepare<T, OFF, SLAB>(g, x, y, gz, wx, wy, w_c, t_step);
         bool oob = fluid && (tu.oob || tv.oob || tw.oob);
-        const Taps<T> gu = trace_gather(g, qu, tu), gv = trace_gather(g, qv, tv), gw = trace_gather(g, qw, tw);
-        const T su = trace_combine(tu, gu), sv = trace_combine(tv, gv), sw = trace_combine(tw, gw);
+        const T su = fast_sample<T, OFF>(g, qu, tu, sy, sz), sv = fast_sample<T, OFF>(g, qv, tv, sy, sz),
+                sw = fast_sample<T, OFF>(g, qw, tw, sy, sz);
         if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
         // main.cpp:284-289
         T uc, vc, wc;
@@ -397,12 +516,18 @@ k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __
         } else {
             uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
         }
-        const Trace<T> td = trace_prepare(g, x, y, gz, uc, vc, wc, t_step);
-        const T sd = trace_combine(td, trace_gather(g, qd, td));
+        const FastTrace<T, OFF> td = fast_prepare<T, OFF, SLAB>(g, x, y, gz, uc, vc, wc, t_step);
+        const T sd = fast_sample<T, OFF>(g, qd, td, sy, sz);
         if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || td.oob; }
-        if (oob) *oob_flag = 1;
+        if (SLAB && oob) *oob_flag = 1;
     }
-    ou[i] = nu; ov[i] = nv; ow[i] = nw; od[i] = nd;
+    T* pu = const_cast<T*>(at_byte<T, OFF>(ou, i)); T* pv = const_cast<T*>(at_byte<T, OFF>(ov, i));
+    T* pw = const_cast<T*>(at_byte<T, OFF>(ow, i)); T* pd = const_cast<T*>(at_byte<T, OFF>(od, i));
+    *pu = nu; *pv = nv; *pw = nw; *pd = nd;
+    if (cu) {
+        *const_cast<T*>(at_byte<T, OFF>(cu, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(cv, i)) = nv;
+        *const_cast<T*>(at_byte<T, OFF>(cw, i)) = nw;
+    }
 }
 
 // Reflection about the projected field (Zehnder et al. 2018, Alg. 1):

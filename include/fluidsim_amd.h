@@ -74,6 +74,13 @@ enum {
     FS_SWEEP_FUSED_LDS = 2   /* both colours in one pass, always the LDS-window kernel             */
 };
 
+/* implementation of the semi-Lagrangian advection (same result bit for bit) */
+enum {
+    FS_ADVECT_TILED = 0,     /* fields staged through LDS plane by plane; samples whose backtrace
+                                leaves the staged window (|v| dt >= 1 cell) use direct loads       */
+    FS_ADVECT_DIRECT = 1     /* every tap a global load                                            */
+};
+
 /* step variants of fs3d_advance */
 enum {
     FS_STEP_REFERENCE = 0,   /* project, then self-advect: FluidSim::update (main.cpp:102-130)   */
@@ -93,7 +100,7 @@ typedef struct fs3d_config {
     int32_t local_slabs;  /* >= 1: cut this handle's planes into that many z-slabs on its own GPU
                              (exercises the multi-GPU slab path inside one process)            */
     int32_t sweep_kernel; /* FS_SWEEP_*                                                           */
-    int32_t reserved;
+    int32_t advect_kernel;/* FS_ADVECT_*                                                          */
     double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
     double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
     double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */

@@ -97,20 +97,41 @@ def test_residual_matches_oracle(fsamd):
     assert np.array_equal(div[1:-1, 1:-1, 1:-1], ref)
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-def test_semi_lagrange_bit_exact(fsamd, shape):
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("scale", [60.0, 12.0])
+@pytest.mark.parametrize("shape", SHAPES + [(140, 21, 40)])
+def test_semi_lagrange_bit_exact(fsamd, shape, scale, kernel):
     nx, ny, nz = shape
-    # velocities of several cells per step so that backtraces cross many cells and leave the grid
-    o, g = make_pair(fsamd, nx, ny, nz, seed=5, scale=60.0)
+    # scale 60: velocities of several cells per step, so that backtraces cross many cells, leave the grid and
+    # leave the window the tiled kernel stages; scale 12: most backtraces stay inside it
+    o, g = make_pair(fsamd, nx, ny, nz, seed=5, scale=scale, advect_kernel=kernel)
     for it in range(2):
         o.semi_lagrange(1.0 / 30.0)
         g.semi_lagrange(1.0 / 30.0)
         assert_fields_equal(o, g, what=f"semi_lagrange {it} {shape}")
 
 
-def test_semi_lagrange_non_finite_samples_read_as_zero(fsamd):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_semi_lagrange_far_backtrace(fsamd, kernel):
+    # a backtrace that ends beyond 2^24 cells: (n - b)/(t - b) of main.cpp:391-393 divides by 0 or 2 there
+    o, g = make_pair(fsamd, 20, 12, 10, seed=15, scale=3.0, masks=False, advect_kernel=kernel)
+    for k, val in ((0, 3.0e9), (1, -7.0e8), (2, 1.1e9)):
+        f = o.field(k).copy()
+        f[4 + k, 5, 6 + k] = val
+        o.field(k)[...] = f
+        g.set_field(k, f)
+    o.semi_lagrange(1.0 / 30.0)
+    g.semi_lagrange(1.0 / 30.0)
+    for k in range(4):
+        a, b = o.field(k), g.get_field(k)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0))
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_semi_lagrange_non_finite_samples_read_as_zero(fsamd, kernel):
     # main.cpp:430-434
-    o, g = make_pair(fsamd, 20, 14, 10, seed=6, scale=20.0)
+    o, g = make_pair(fsamd, 20, 14, 10, seed=6, scale=20.0, advect_kernel=kernel)
     for k in range(4):
         f = o.field(k).copy()
         f[3, 5, 7] = np.nan

@@ -593,7 +593,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
 // generation's velocity into the other generation, then swaps generations.
 template <typename T, typename OFF, bool SLAB>
 int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, int cv, int ov, int cd, int od, T t_step,
-                  int density_mode, bool copy_to_tmp) {
+                  int density_mode, bool copy_to_tmp, bool reflect) {
     // the owned planes, shell included, so that the new generation is complete
     const int zb = p.H, ze = p.H + p.own_planes();
     T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
@@ -610,13 +610,16 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
     auto go = [&](auto kern, size_t lds) -> int {
         SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int tiles = div_up(s->nx, 64) * div_up(s->ny, 8);
-        const int nchunks = pick_chunks(ze - zb, tiles, 2 * s->num_cus);
+        // workgroups a CU holds at once: limited by LDS (160 KiB) and, at 72 registers, to 3 x 8 waves
+        const int per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / lds)));
+        const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus);
         const int zchunk = div_up(ze - zb, nchunks);
         dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), div_up(ze - zb, zchunk));
         hipLaunchKernelGGL(kern, g, b, lds, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0), F<T>(p, ov, 1),
                            F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob);
         return FS_OK;
     };
+    if (reflect) return go(k_advect_tiled<T, OFF, true, SLAB, true>, AdvTile<T, true>::lds_bytes());
     if (qu == U) return go(k_advect_tiled<T, OFF, false, SLAB>, AdvTile<T, false>::lds_bytes());
     return go(k_advect_tiled<T, OFF, true, SLAB>, AdvTile<T, true>::lds_bytes());
 }
@@ -624,7 +627,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
 // copy_to_tmp: the new velocity is also written to the scratch fields (the unprojected half-step
 // field the reflection needs later).
 template <typename T>
-int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false) {
+int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false, bool reflect = false) {
     FS_TRY(prepare(s));
     if (s->nparts_global > 1) {
         FS_TRY(exchange_state_halos(s));
@@ -638,10 +641,10 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
         const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
         const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
         const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
-        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
-        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
-        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
-        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp)));
+        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
+        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
+        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
+        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
     }
     SIM_HIP(hipGetLastError());
     s->curv = ov;
@@ -690,12 +693,17 @@ int step(fs3d_sim* s, double dt) {
         FS_TRY(advect<T>(s, 0.5 * dt, false, 0, true));   // ut goes to the scratch fields as well
         FS_TRY(project<T>(s, nullptr, nullptr, 1));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
-        for (Part& p : s->parts)
-            hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
-                               F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
-                               (const T*)p.tmp[2], (T*)p.tmp[0], (T*)p.tmp[1], (T*)p.tmp[2]);
-        SIM_HIP(hipGetLastError());
-        FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
+        if (s->cfg.advect_kernel == FS_ADVECT_TILED) {
+            // the staged kernel forms ur while it loads ut and uh: no reflection pass
+            FS_TRY(advect<T>(s, 0.5 * dt, true, 0, false, true));
+        } else {
+            for (Part& p : s->parts)
+                hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
+                                   F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
+                                   (const T*)p.tmp[2], (T*)p.tmp[0], (T*)p.tmp[1], (T*)p.tmp[2]);
+            SIM_HIP(hipGetLastError());
+            FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
+        }
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     }

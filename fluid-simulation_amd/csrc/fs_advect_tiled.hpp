@@ -31,7 +31,9 @@ struct AdvTile {
 };
 
 // SEP: the carrying velocity (U,V,W) is not (qu,qv,qw).  SLAB: the arrays hold only some planes of the grid.
-template <typename T, typename OFF, bool SEP, bool SLAB>
+// REFL (needs SEP): the carried velocity is the reflection 2*(U,V,W) - (qu,qv,qw) of the given field about
+// the carrying one (Zehnder et al. 2018, Alg. 1), formed while staging instead of by a pass of its own.
+template <typename T, typename OFF, bool SEP, bool SLAB, bool REFL = false>
 __global__ void __launch_bounds__(512)
 k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
                const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
@@ -73,6 +75,13 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         }
     };
     auto commit = [&](int p) {   // registers -> LDS
+        if (REFL) {
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                stage[f][0] = (T)2 * stage[4 + f][0] - stage[f][0];
+                stage[f][1] = (T)2 * stage[4 + f][1] - stage[f][1];
+            }
+        }
         T* dst = L + (p & (NPL - 1)) * PS + tid;
 #pragma unroll
         for (int f = 0; f < C::NF; ++f) dst[f * NPL * PS] = stage[f][0];
@@ -110,6 +119,15 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const volatile T* r11 = at_byte(src[f], trace_base(g, tr) + sz + sy);
             t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
             t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
+            if (REFL && f < 3) {
+                const volatile T* c00 = at_byte(src[4 + f], trace_base(g, tr));
+                const volatile T* c10 = at_byte(src[4 + f], trace_base(g, tr) + sy);
+                const volatile T* c01 = at_byte(src[4 + f], trace_base(g, tr) + sz);
+                const volatile T* c11 = at_byte(src[4 + f], trace_base(g, tr) + sz + sy);
+                t.s[0] = (T)2 * c00[0] - t.s[0]; t.s[1] = (T)2 * c00[1] - t.s[1]; t.s[2] = (T)2 * c10[0] - t.s[2];
+                t.s[3] = (T)2 * c01[0] - t.s[3]; t.s[4] = (T)2 * c10[1] - t.s[4]; t.s[5] = (T)2 * c01[1] - t.s[5];
+                t.s[6] = (T)2 * c11[0] - t.s[6]; t.s[7] = (T)2 * c11[1] - t.s[7];
+            }
         }
         return fast_finish(tr, t);
     };

@@ -200,7 +200,8 @@ def test_lexicographic_update_reproduces_recorded_sweep_counts(fsamd):
 
 
 def reflection_step_oracle(o, dt, tol, max_iter):
-    """The reflection step restated with oracle primitives (see DESIGN.md, step driver)."""
+    """The reflection step restated with oracle primitives: project, half advection, project, reflect about
+    the projected field, half advection of the reflected field along the projected one."""
     o.project_rb(stop_mode=1, tol=tol, max_iter=max_iter)
     u0 = [o.field(k).copy() for k in range(4)]
     half = o.advect(0.5 * dt, u0, u0[:3], 0)
@@ -215,16 +216,29 @@ def reflection_step_oracle(o, dt, tol, max_iter):
         o.field(k)[...] = out[k]
 
 
-def test_reflection_step_matches_oracle(fsamd):
+@pytest.mark.parametrize("kernel", [0, 1], ids=["tiled", "direct"])
+def test_reflection_step_matches_oracle(fsamd, kernel):
     n = 24
     o = Oracle3D(n, n, n)
-    g = fsamd.FluidSim3D(n, n, n, step_mode=1, tol=0.5)
+    g = fsamd.FluidSim3D(n, n, n, step_mode=1, tol=0.5, advect_kernel=kernel)
     o.sphere_influence(n / 10.0); g.sphere_influence(n / 10.0)
     for step in range(3):
         reflection_step_oracle(o, 1.0 / 30.0, 0.5, 1000)
         g.advance(1.0 / 30.0)
         assert_fields_equal(o, g, what=f"reflection step {step}")
     assert g.getStep() == 3 and g.getTime() == pytest.approx(0.1)
+
+
+@pytest.mark.parametrize("kernel", [0, 1], ids=["tiled", "direct"])
+@pytest.mark.parametrize("scale", [20.0, 90.0])
+def test_reflection_step_random_state_matches_oracle(fsamd, kernel, scale):
+    # random masks and velocities; at scale 90 a half step moves up to 1.5 cells, so part of the samples
+    # leave the window the tiled kernel stages and the reflected field is formed from direct loads
+    o, g = make_pair(fsamd, 70, 19, 13, seed=21, scale=scale, step_mode=1, tol=50.0, max_iters=30, advect_kernel=kernel)
+    for step in range(2):
+        reflection_step_oracle(o, 1.0 / 30.0, 50.0, 30)
+        g.advance(1.0 / 30.0)
+        assert_fields_equal(o, g, what=f"reflection step {step}")
 
 
 def test_projection_converges_on_a_compatible_problem(fsamd):
@@ -248,7 +262,7 @@ def test_local_slabs_bitwise_equal_single_domain(fsamd, slabs, kernel):
     # z-slab decomposition (halo planes, interface w exchange, halo refresh before advection) must not
     # change a single bit: red-black ordering is partition independent
     nx, ny, nz = 28, 18, 23
-    _, g1 = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, sweep_kernel=1)
+    _, g1 = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, sweep_kernel=1, advect_kernel=1)
     _, gs = make_pair(fsamd, nx, ny, nz, seed=9, scale=20.0, local_slabs=slabs, sweep_kernel=kernel)
     for mode in (0, 1):
         g1.set_config(step_mode=mode, tol=1.0)

@@ -1,6 +1,6 @@
 """CPU tests of the oracle: the restatement against the known answers recorded from the reference
 binary (tests/golden/ref3d_recorded_kats.json), and the invariants that follow from the reference's
-code (SURVEY section 4 of the project documentation lists them)."""
+code (mask rules, emitter, sampler, reflection identities)."""
 import json
 import os
 

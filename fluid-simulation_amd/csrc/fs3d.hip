@@ -471,19 +471,27 @@ __global__ void k_combine_parts(const double* __restrict__ dres, int nparts, dou
     }
 }
 
+// An advection of a slab does not wait for its out-of-halo flag; the flag comes back with the next
+// reduction result or synchronisation and stays set until the handle is reset.
+int oob_status(fs3d_sim* s) {
+    if (s->nparts_global > 1 && *s->hoob) return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells)");
+    return FS_OK;
+}
+
 int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
     double* comb = s->dres + 2 * s->nlocal;
     hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
     SIM_HIP(hipGetLastError());
     if (s->nranks > 1) {
         FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm, s->stream), "ncclAllReduce"));
-        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
+        if (mx)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
+            FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
     }
-    SIM_HIP(hipMemcpyAsync(s->hres, comb, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     SIM_HIP(hipStreamSynchronize(s->stream));
     if (sum) *sum = s->hres[0];
     if (mx) *mx = s->hres[1];
-    return FS_OK;
+    return oob_status(s);
 }
 
 template <typename T>
@@ -529,7 +537,7 @@ int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
     }
     SIM_HIP(hipGetLastError());
     double sum = 0, mx = 0;
-    FS_TRY(finish_reduction(s, &sum, &mx));
+    FS_TRY(finish_reduction(s, &sum, max_abs ? &mx : nullptr));
     const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
     if (l2) *l2 = sqrt(sum) / ninterior;   // 3_fluid/FluidSim.cpp:40-43
     if (max_abs) *max_abs = mx;
@@ -634,7 +642,6 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
         if (q_from_tmp) FS_TRY(exchange_halos(s, {{base_tmp, 0, s->esz}, {base_tmp, 1, s->esz}, {base_tmp, 2, s->esz}}));
     }
     const bool slab = s->nparts_global > 1;
-    if (slab) SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
     for (Part& p : s->parts) {
         const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
@@ -650,12 +657,7 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
     s->curv = ov;
     s->curd = od;
     s->halo_dirty = s->nparts_global > 1;
-    if (slab) {   // a backtrace beyond the halo cannot be served: report it
-        SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        SIM_HIP(hipStreamSynchronize(s->stream));
-        if (*s->hoob) return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells)");
-    }
-    return FS_OK;
+    return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }
 
 template <typename T>
@@ -887,10 +889,13 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     SIM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_bnd, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
-    SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 2)));
-    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 2, hipHostMallocDefault));
-    SIM_HIP(hipMalloc((void**)&s->doob, sizeof(int)));
-    SIM_HIP(hipHostMalloc((void**)&s->hoob, sizeof(int), hipHostMallocDefault));
+    SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 3)));
+    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 3, hipHostMallocDefault));
+    // the out-of-halo flag sits behind the combined pair, so that the copy of a reduction result brings it along
+    s->doob = reinterpret_cast<int*>(s->dres + 2 * s->nlocal + 2);
+    s->hoob = reinterpret_cast<int*>(s->hres + 2);
+    SIM_HIP(hipMemset(s->doob, 0, sizeof(double)));
+    *s->hoob = 0;
     if (nranks > 1) {
         s->rccl = Rccl::get(s->err);
         if (!s->rccl) return FS_ECOMM;
@@ -1015,9 +1020,8 @@ void fs3d_destroy(fs3d_sim* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
     free_parts(s);
-    (void)hipFree(s->dres); (void)hipFree(s->doob);
+    (void)hipFree(s->dres);
     if (s->hres) (void)hipHostFree(s->hres);
-    if (s->hoob) (void)hipHostFree(s->hoob);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     if (s->comm_stream) { (void)hipStreamSynchronize(s->comm_stream); (void)hipStreamDestroy(s->comm_stream); }
     if (s->ev_bnd) (void)hipEventDestroy(s->ev_bnd);
@@ -1033,6 +1037,8 @@ int fs3d_reset(fs3d_sim* s) {
     s->curv = 0;
     s->curd = 0;
     s->sweep_hint[0] = s->sweep_hint[1] = 1;
+    SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
+    *s->hoob = 0;
     s->stats = fs3d_stats{};
     s->halo_dirty = true;
     SIM_HIP(hipStreamSynchronize(s->stream));
@@ -1289,8 +1295,10 @@ int fs3d_get_stats(fs3d_sim* s, fs3d_stats* out) {
 
 int fs3d_synchronize(fs3d_sim* s) {
     SIM_GUARD(s);
+    if (s->nparts_global > 1)
+        SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     SIM_HIP(hipStreamSynchronize(s->stream));
-    return FS_OK;
+    return oob_status(s);
 }
 
 }  // extern "C"

@@ -191,7 +191,11 @@ int fs3d_update(fs3d_sim *sim, double t_step);
  * step_mode of length dt, then time += dt, step += 1.                       */
 int fs3d_advance(fs3d_sim *sim, double dt);
 int fs3d_get_stats(fs3d_sim *sim, fs3d_stats *out);
-/* Blocks until all work queued on the handle has finished.                  */
+/* Blocks until all work queued on the handle has finished.  On a slab handle
+ * an advection whose backtrace needed a plane beyond the two halo planes
+ * (|v| dt > 2 cells at a slab interface) is not waited for when it is queued:
+ * this call, and any projection that evaluates its stopping metric, returns
+ * FS_ESTATE for it, until fs3d_reset.                                        */
 int fs3d_synchronize(fs3d_sim *sim);
 
 /* z-slab decomposition over the GPUs of one node (no counterpart in the

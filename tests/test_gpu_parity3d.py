@@ -354,3 +354,18 @@ def test_rccl_binding_loopback(fsamd):
     # all-reduce and a grouped send/receive
     assert fsamd.load_library().fsamd_comm_selftest(0) == 0
     assert len(fsamd.comm_unique_id()) == 128
+
+
+def test_backtrace_beyond_the_slab_halo_is_reported(fsamd):
+    # a slab holds two halo planes; a backtrace that needs a plane beyond them cannot be served.  The
+    # advection does not wait for the flag: the next call that synchronises reports it.
+    _, g = make_pair(fsamd, 20, 12, 24, seed=31, scale=1.0, masks=False, local_slabs=3)
+    w = g.get_field(2)
+    w[10:14, 4:8, 5:9] = 200.0          # 200 cells/s * 1/30 s: more than 6 planes
+    g.set_field(2, w)
+    g.semi_lagrange(1.0 / 30.0)
+    with pytest.raises(fsamd.FluidSimError, match="halo"):
+        g.synchronize()
+    g.reset()                            # clears the flag
+    g.semi_lagrange(1.0 / 30.0)
+    g.synchronize()

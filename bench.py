@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=0, help="cubic grid size override")
+    ap.add_argument("--local-slabs", type=int, default=1,
+                    help="cut each rank's planes into this many z-slabs on its own GPU (rehearses the slab path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--max-iters", type=int, default=1000)
@@ -114,7 +116,7 @@ def main():
     sim = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
                         dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
-                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode,
+                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode, local_slabs=a.local_slabs,
                         buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
     scene_init, scene_step = scenes.SCENES[a.scene]
     scene_init(sim)
@@ -175,7 +177,7 @@ def main():
                             f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, "
                             + ("residual evaluated from one sweep before the previous step's count, then every sweep"
                                if a.check_every == 0 else f"checked every {a.check_every}"),
-                "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}",
+                "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}" + (f" (x{a.local_slabs} slabs per GPU)" if a.local_slabs > 1 else ""),
                 "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
                 "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
             },

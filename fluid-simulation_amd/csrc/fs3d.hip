@@ -64,7 +64,8 @@ struct fs3d_sim {
     int rank = 0, nranks = 1, nlocal = 1, nparts_global = 1;
     std::vector<Part> parts;
     int curv = 0, curd = 0;      // generation holding the current velocity (u,v,w) / density
-    bool cells_dirty = true, halo_dirty = true;
+    bool cells_dirty = true;
+    int halo_dirty = 3;          // halo planes that lag their owners: bit 0 velocity, bit 1 density
     double* dres = nullptr;      // 2 doubles per local part + 2 combined
     double* hres = nullptr;      // pinned mirror of the combined pair
     int* doob = nullptr;         // device flag: a backtrace left the slab's halo
@@ -238,12 +239,26 @@ void* base_flags(fs3d_sim*, Part& p, int) { return p.flags; }
 void* base_tmp(fs3d_sim*, Part& p, int k) { return p.tmp[k]; }
 void* base_cells(fs3d_sim*, Part& p, int) { return p.cells; }
 
-int exchange_state_halos(fs3d_sim* s) {
+enum { HALO_VEL = 1, HALO_DEN = 2, HALO_ALL = 3 };
+
+// Brings the halo planes named in `need` up to date if they lag; `with_tmp` adds the scratch velocity.
+int refresh_halos(fs3d_sim* s, int need, bool with_tmp = false) {
+    if (s->nparts_global == 1) { s->halo_dirty = 0; return FS_OK; }
+    const int todo = s->halo_dirty & need;
     std::vector<HaloOp> ops;
-    for (int k = 0; k < 4; ++k) ops.push_back({base_field_cur, k, s->esz});
-    FS_TRY(exchange_halos(s, ops));
-    s->halo_dirty = false;
+    if (todo & HALO_VEL) for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
+    if (todo & HALO_DEN) ops.push_back({base_field_cur, 3, s->esz});
+    if (with_tmp) for (int k = 0; k < 3; ++k) ops.push_back({base_tmp, k, s->esz});
+    if (!ops.empty()) FS_TRY(exchange_halos(s, ops));
+    s->halo_dirty &= ~todo;
     return FS_OK;
+}
+
+// After sweeps: the one-pass sweeps leave the velocity halos exchanged, the two-pass and the
+// lexicographic ones only keep the interface w plane current.
+void halos_after_sweeps(fs3d_sim* s) {
+    const bool one_pass = s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
+    if (s->nparts_global > 1 && !one_pass) s->halo_dirty |= HALO_VEL;
 }
 
 int refresh_flags(fs3d_sim* s) {
@@ -261,10 +276,9 @@ int refresh_flags(fs3d_sim* s) {
 }
 
 // Everything a compute entry point needs before its first kernel.
-int prepare(fs3d_sim* s) {
+int prepare(fs3d_sim* s, int need = HALO_VEL, bool with_tmp = false) {
     FS_TRY(refresh_flags(s));
-    if (s->halo_dirty) FS_TRY(exchange_state_halos(s));
-    return FS_OK;
+    return refresh_halos(s, need, with_tmp);
 }
 
 // ---- projection -----------------------------------------------------------
@@ -326,36 +340,31 @@ int launch_halfsweep(fs3d_sim* s, int colour) {
 }
 
 // One full red-black sweep in a single pass over HBM: the kernels read the current velocity generation
-// and write the other one, then the roles swap.  `launch(part, z0, z1)` runs the kernel for the stored
-// plane range [z0, z1).  Slabs recompute the two ghost planes below them (and one above) instead of
-// exchanging per colour.  With more than one slab the two owned planes next to each interface are
-// produced first, their exchange runs on a second stream, and the interior of the slab is swept
-// meanwhile; the main stream picks the halos up before anything reads them.
+// and write the other one, then the roles swap.  `launch(part, z0, z1, stream)` runs the kernel for the
+// stored plane range [z0, z1).  Slabs recompute the two ghost planes below them (and one above) instead
+// of exchanging per colour.  With more than one slab the two owned planes next to each interface are
+// produced on the second stream, followed there by their exchange, while the main stream sweeps the
+// interior of the slab; the main stream picks the halos up before anything reads them.
 template <typename Launch>
 int one_pass_driver(fs3d_sim* s, Launch launch) {
     if (s->nparts_global == 1) {
-        for (Part& p : s->parts) launch(p, 0, p.g.nzl);
+        for (Part& p : s->parts) launch(p, 0, p.g.nzl, s->stream);
         SIM_HIP(hipGetLastError());
         s->curv ^= 1;
         return FS_OK;
     }
-    struct Mid { int b, e; };
-    std::vector<Mid> mid;
+    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));               // everything queued so far
+    SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
     for (Part& p : s->parts) {
         const int own_lo = p.H, own_hi = p.H + p.own_planes();
         const int lo_end = p.has_lo ? std::min(own_lo + 2, own_hi) : own_lo;
         const int hi_beg = p.has_hi ? std::max(own_hi - 2, lo_end) : own_hi;
-        if (lo_end > own_lo) launch(p, own_lo, lo_end);
-        if (own_hi > hi_beg) launch(p, hi_beg, own_hi);
-        mid.push_back({lo_end, hi_beg});
+        if (lo_end > own_lo) launch(p, own_lo, lo_end, s->comm_stream);
+        if (own_hi > hi_beg) launch(p, hi_beg, own_hi, s->comm_stream);
+        if (hi_beg > lo_end) launch(p, lo_end, hi_beg, s->stream);
     }
     SIM_HIP(hipGetLastError());
-    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));
-    for (size_t k = 0; k < s->parts.size(); ++k)
-        if (mid[k].e > mid[k].b) launch(s->parts[k], mid[k].b, mid[k].e);
-    SIM_HIP(hipGetLastError());
     s->curv ^= 1;   // the halo operators below address the new generation
-    SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
     std::vector<HaloOp> ops;
     for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
     FS_TRY(exchange_halos(s, ops, s->comm_stream));
@@ -397,13 +406,13 @@ int launch_fused_sweep(fs3d_sim* s) {
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
     const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
-    return one_pass_driver(s, [&](Part& p, int z0, int z1) {
+    return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
         FusedRanges r = fused_ranges<T>(p);
         r.z0 = z0; r.z1 = z1;
         const int nchunks = pick_chunks(z1 - z0, tiles, 2 * s->num_cus);
         r.zchunk = div_up(z1 - z0, nchunks);
         dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), div_up(z1 - z0, r.zchunk));
-        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
+        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
                            F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r);
     });
 }
@@ -422,13 +431,13 @@ int launch_rows_sweep(fs3d_sim* s) {
     const int rows = std::min(C::RY, s->ny);
     const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
     const int nty = s->ny <= rows ? 1 : div_up(s->ny - 4, rows - 4);
-    return one_pass_driver(s, [&](Part& p, int z0, int z1) {
+    return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
         FusedRanges r = fused_ranges<T>(p);
         r.z0 = z0; r.z1 = z1;
         const int nchunks = pick_chunks(z1 - z0, ntx * nty, s->num_cus);
         r.zchunk = div_up(z1 - z0, nchunks);
         dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
-        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
+        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
                            F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty, rows);
     });
 }
@@ -590,7 +599,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
     s->stats.sweeps = it;
     s->stats.sweeps_step += it;
     s->stats.metric = metric;
-    s->halo_dirty = s->nparts_global > 1;   // only the interface w plane was kept current
+    halos_after_sweeps(s);
     if (sweeps_out) *sweeps_out = it;
     if (metric_out) *metric_out = metric;
     return FS_OK;
@@ -636,11 +645,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
 // field the reflection needs later).
 template <typename T>
 int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false, bool reflect = false) {
-    FS_TRY(prepare(s));
-    if (s->nparts_global > 1) {
-        FS_TRY(exchange_state_halos(s));
-        if (q_from_tmp) FS_TRY(exchange_halos(s, {{base_tmp, 0, s->esz}, {base_tmp, 1, s->esz}, {base_tmp, 2, s->esz}}));
-    }
+    FS_TRY(prepare(s, HALO_ALL, q_from_tmp));
     const bool slab = s->nparts_global > 1;
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
     for (Part& p : s->parts) {
@@ -656,7 +661,7 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
     SIM_HIP(hipGetLastError());
     s->curv = ov;
     s->curd = od;
-    s->halo_dirty = s->nparts_global > 1;
+    s->halo_dirty = HALO_ALL;
     return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }
 
@@ -670,7 +675,7 @@ int buoyancy(fs3d_sim* s, double dt) {
                            (T)(0.1 * s->cfg.buoyancy), p.zb, p.ze);
     }
     SIM_HIP(hipGetLastError());
-    s->halo_dirty = s->nparts_global > 1;
+    s->halo_dirty |= HALO_VEL;
     return FS_OK;
 }
 
@@ -1040,7 +1045,7 @@ int fs3d_reset(fs3d_sim* s) {
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
     *s->hoob = 0;
     s->stats = fs3d_stats{};
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     SIM_HIP(hipStreamSynchronize(s->stream));
     return FS_OK;
 }
@@ -1081,7 +1086,7 @@ int fs3d_set_field(fs3d_sim* s, int which, const void* host, size_t count) {
         const char* src = (const char*)host + (size_t)(p.z0 - z0) * plane * s->esz;
         SIM_HIP(hipMemcpy(dst, src, (size_t)p.own_planes() * plane * s->esz, hipMemcpyHostToDevice));
     }
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return FS_OK;
 }
 
@@ -1160,7 +1165,7 @@ int fs3d_get_cell_types(fs3d_sim* s, uint8_t* host, size_t count) {
 int fs3d_sphere_emitter(fs3d_sim* s, float radius, float cx, float cy, float cz, float strength) {
     SIM_GUARD(s);
     if (!(radius > 0)) return set_err(s, FS_EINVAL, "radius must be positive");
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return DISPATCH(s, sphere_emitter, s, radius, cx, cy, cz, strength);
 }
 
@@ -1184,7 +1189,7 @@ int fs3d_sphere_influence(fs3d_sim* s, float radius) {
 int fs3d_fill_sphere(fs3d_sim* s, float radius, float cx, float cy, float cz, int iter) {
     SIM_GUARD(s);
     if (iter % 100 != 0) return FS_OK;   // main.cpp:69
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return DISPATCH(s, fill_sphere, s, radius, cx, cy, cz);
 }
 
@@ -1195,13 +1200,13 @@ int fs3d_fill_sphere_influence(fs3d_sim* s, float radius, int iter) {
 
 int fs3d_bottom_influence(fs3d_sim* s) {
     SIM_GUARD(s);
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return DISPATCH(s, scene_kernel, s, 0, nullptr);
 }
 
 int fs3d_clear(fs3d_sim* s) {
     SIM_GUARD(s);
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return DISPATCH(s, scene_kernel, s, 1, nullptr);
 }
 
@@ -1212,7 +1217,7 @@ int fs3d_apply_source(fs3d_sim* s, double xmin, double xmax, double ymin, double
                   (int)(zmin * s->nz), (int)(zmax * s->nz)};
     if (box[0] < 0 || box[2] < 0 || box[4] < 0 || box[1] > s->nx || box[3] > s->ny || box[5] > s->nz)
         return set_err(s, FS_EINVAL, "source box outside the grid");
-    s->halo_dirty = true;
+    s->halo_dirty = HALO_ALL;
     return DISPATCH(s, scene_kernel, s, 2, box);
 }
 
@@ -1221,7 +1226,7 @@ int fs3d_gauss_seidel_projection(fs3d_sim* s, double* change) {
     FS_TRY(prepare(s));
     double c = 0;
     FS_TRY(DISPATCH(s, sweep_with_change, s, &c));
-    s->halo_dirty = s->nparts_global > 1;
+    halos_after_sweeps(s);
     if (change) *change = c;
     return FS_OK;
 }
@@ -1230,7 +1235,7 @@ int fs3d_sweeps(fs3d_sim* s, int n) {
     SIM_GUARD(s);
     FS_TRY(prepare(s));
     for (int i = 0; i < n; ++i) FS_TRY(DISPATCH(s, sweep_once, s));
-    s->halo_dirty = s->nparts_global > 1;
+    halos_after_sweeps(s);
     return FS_OK;
 }
 
@@ -1243,7 +1248,7 @@ int fs3d_time_sweeps(fs3d_sim* s, int n, double* ms) {
     SIM_HIP(hipEventSynchronize(s->ev[1]));
     float t = 0;
     SIM_HIP(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
-    s->halo_dirty = s->nparts_global > 1;
+    halos_after_sweeps(s);
     if (ms) *ms = t;
     return FS_OK;
 }

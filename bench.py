@@ -179,6 +179,7 @@ def main():
                                if a.check_every == 0 else f"checked every {a.check_every}"),
                 "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}" + (f" (x{a.local_slabs} slabs per GPU)" if a.local_slabs > 1 else ""),
                 "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
+                "residual_norm": "sqrt(sum (div/dt)^2) / #interior cells, the norm of 3_fluid/FluidSim.cpp:25-43",
                 "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
             },
             "roofline": {

@@ -30,6 +30,7 @@ STOP_FIXED, STOP_L1_CHANGE, STOP_L2_RESIDUAL = 0, 1, 2
 STEP_REFERENCE, STEP_REFLECTION = 0, 1
 SWEEP_FUSED, SWEEP_TWO_PASS, SWEEP_FUSED_LDS = 0, 1, 2
 ADVECT_TILED, ADVECT_DIRECT = 0, 1
+ADVECTION_SEMI_LAGRANGE, ADVECTION_MACCORMACK = 0, 1
 COMM_ID_BYTES = 128
 
 # every symbol include/fluidsim_amd.h declares
@@ -50,7 +51,7 @@ class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("dtype", C.c_int32), ("ordering", C.c_int32), ("stop_mode", C.c_int32),
         ("max_iters", C.c_int32), ("check_every", C.c_int32), ("step_mode", C.c_int32), ("local_slabs", C.c_int32),
-        ("sweep_kernel", C.c_int32), ("advect_kernel", C.c_int32),
+        ("sweep_kernel", C.c_int32), ("advect_kernel", C.c_int32), ("advection", C.c_int32), ("reserved", C.c_int32),
         ("tol", C.c_double), ("omega", C.c_double), ("buoyancy", C.c_double),
     ]
 

@@ -43,6 +43,7 @@ struct Part {
     size_t n = 0;         // local element count
     void* f[2][4] = {{nullptr}};
     void* tmp[3] = {nullptr};
+    void* mc[4] = {nullptr};   // outputs of the MacCormack pass, allocated when the scheme is first used
     uint8_t* cells = nullptr;
     uint8_t* flags = nullptr;
     void* recv_lo = nullptr;   // staging for the interface w plane from the lower / upper rank
@@ -108,6 +109,7 @@ void free_parts(fs3d_sim* s) {
         for (int g = 0; g < 2; ++g)
             for (int k = 0; k < 4; ++k) (void)hipFree(p.f[g][k]);
         for (int k = 0; k < 3; ++k) (void)hipFree(p.tmp[k]);
+        for (int k = 0; k < 4; ++k) (void)hipFree(p.mc[k]);
         (void)hipFree(p.cells); (void)hipFree(p.flags);
         (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
         (void)hipFree(p.partials);
@@ -679,17 +681,50 @@ int buoyancy(fs3d_sim* s, double dt) {
     return FS_OK;
 }
 
+// The MacCormack pass after an advection (fs_kernels3d.hpp, k_maccormack): q = what the advection
+// carried (the previous generation, or the scratch velocity with the previous density), the carrying
+// velocity = the previous generation's, f = the current generation.  The corrected fields become the
+// current generation; copy_to_tmp also leaves the corrected velocity in the scratch fields.
+template <typename T>
+int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
+    for (Part& p : s->parts)
+        for (int k = 0; k < 4; ++k)
+            if (!p.mc[k]) SIM_HIP(hipMalloc(&p.mc[k], p.n * s->esz));
+    FS_TRY(prepare(s, HALO_ALL));   // the backward trace reads the halo planes of the forward result
+    const int cv = s->curv, pv = s->curv ^ 1, cd = s->curd, pd = s->curd ^ 1;
+    for (Part& p : s->parts) {
+        const int zb = p.H, ze = p.H + p.own_planes();
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
+        const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, pv, 0);
+        const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, pv, 1);
+        const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, pv, 2);
+        T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
+        T* c1 = copy_to_tmp ? (T*)p.tmp[1] : nullptr;
+        T* c2 = copy_to_tmp ? (T*)p.tmp[2] : nullptr;
+        hipLaunchKernelGGL(k_maccormack<T>, g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, pd, 3), F<T>(p, pv, 0), F<T>(p, pv, 1),
+                           F<T>(p, pv, 2), F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, cd, 3), (T*)p.mc[0],
+                           (T*)p.mc[1], (T*)p.mc[2], (T*)p.mc[3], c0, c1, c2, p.flags, (T)t_step, zb, s->doob);
+        for (int k = 0; k < 3; ++k) std::swap(p.f[cv][k], p.mc[k]);
+        std::swap(p.f[cd][3], p.mc[3]);
+    }
+    SIM_HIP(hipGetLastError());
+    s->halo_dirty = HALO_ALL;
+    return FS_OK;
+}
+
 template <typename T>
 int step(fs3d_sim* s, double dt) {
     s->stats.sweeps_step = 0;
     s->resid_dt = dt > 0 ? dt : 1.0;
     SIM_HIP(hipEventRecord(s->ev[0], s->stream));
     if (s->cfg.buoyancy != 0.0) FS_TRY(buoyancy<T>(s, dt));
+    const bool mac = s->cfg.advection == FS_ADVECTION_MACCORMACK;
     if (s->cfg.step_mode == FS_STEP_REFERENCE) {
         // FluidSim::update (main.cpp:102-130)
         FS_TRY(project<T>(s, nullptr, nullptr));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
-        FS_TRY(advect<T>(s, dt, false, 1));
+        FS_TRY(advect<T>(s, dt, false, mac ? 0 : 1));
+        if (mac) FS_TRY(maccormack<T>(s, dt, false, false));
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     } else {
@@ -697,10 +732,11 @@ int step(fs3d_sim* s, double dt) {
         // leaving the advected field for the next step to project:
         //   u0 = P(state); ut = A(u0; u0, dt/2); uh = P(ut); ur = 2 uh - ut; state = A(ur; uh, dt/2)
         FS_TRY(project<T>(s, nullptr, nullptr));
-        FS_TRY(advect<T>(s, 0.5 * dt, false, 0, true));   // ut goes to the scratch fields as well
+        FS_TRY(advect<T>(s, 0.5 * dt, false, 0, !mac));   // ut goes to the scratch fields as well
+        if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, false, true));
         FS_TRY(project<T>(s, nullptr, nullptr, 1));
         SIM_HIP(hipEventRecord(s->ev[1], s->stream));
-        if (s->cfg.advect_kernel == FS_ADVECT_TILED) {
+        if (s->cfg.advect_kernel == FS_ADVECT_TILED && !mac) {
             // the staged kernel forms ur while it loads ut and uh: no reflection pass
             FS_TRY(advect<T>(s, 0.5 * dt, true, 0, false, true));
         } else {
@@ -710,6 +746,7 @@ int step(fs3d_sim* s, double dt) {
                                    (const T*)p.tmp[2], (T*)p.tmp[0], (T*)p.tmp[1], (T*)p.tmp[2]);
             SIM_HIP(hipGetLastError());
             FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
+            if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, true, false));
         }
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
@@ -863,6 +900,7 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (c->advect_kernel < FS_ADVECT_TILED || c->advect_kernel > FS_ADVECT_DIRECT) { *why = "bad advect_kernel"; return false; }
+    if (c->advection < FS_ADVECTION_SEMI_LAGRANGE || c->advection > FS_ADVECTION_MACCORMACK) { *why = "bad advection"; return false; }
     if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
     return true;
 }
@@ -938,6 +976,8 @@ void fs3d_default_config(fs3d_config* c) {
     c->local_slabs = 1;
     c->sweep_kernel = FS_SWEEP_FUSED;
     c->advect_kernel = FS_ADVECT_TILED;
+    c->advection = FS_ADVECTION_SEMI_LAGRANGE;
+    c->reserved = 0;
     c->tol = 5.0;
     c->omega = 1.0;
     c->buoyancy = 0.0;

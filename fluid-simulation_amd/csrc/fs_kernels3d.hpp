@@ -530,6 +530,74 @@ k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __
     }
 }
 
+// MacCormack correction and limiter, the scheme of 3_fluid/FluidSim.cpp:217-389 on the 3D sampler
+// (not in the 3D reference).  q = the field before the forward advection, (U,V,W) the carrying
+// velocity, f the forward result.  One location: b = f traced backwards over -t_step, m = f + (q - b)/2,
+// and m falls back to f where it leaves the range of the eight taps of q the forward trace read (taps
+// that read as the default count as 0).  Locations the advection leaves alone keep f.
+template <typename T>
+__device__ __forceinline__ T maccormack_one(const Grid& g, const T* __restrict__ q, const T* __restrict__ f, int x, int y,
+                                            int gz, T dx, T dy, T dz, T t_step, T q_own, T f_own, bool& oob) {
+    const Trace<T> tb = trace_prepare(g, x, y, gz, dx, dy, dz, -t_step);
+    const T b = trace_combine(tb, trace_gather(g, f, tb));
+    T m = f_own + (T)0.5 * (q_own - b);
+    const Trace<T> tf = trace_prepare(g, x, y, gz, dx, dy, dz, t_step);
+    const Taps<T> a = trace_gather(g, q, tf);
+    T lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const T s = (((tf.ok >> k) & 1u) && isfinite(a.s[k])) ? a.s[k] : (T)0;
+        if (k == 0) { lo = s; hi = s; }
+        lo = s < lo ? s : lo;
+        hi = s > hi ? s : hi;
+    }
+    if (m < lo || m > hi) m = f_own;
+    oob = oob || tb.oob || tf.oob;
+    return m;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_maccormack(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
+             const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
+             const T* __restrict__ fu, const T* __restrict__ fv, const T* __restrict__ fw, const T* __restrict__ fd,
+             T* __restrict__ mu, T* __restrict__ mv, T* __restrict__ mw, T* __restrict__ md, T* __restrict__ cu,
+             T* __restrict__ cv, T* __restrict__ cw, const uint8_t* __restrict__ flags, T t_step, int zb,
+             int* __restrict__ oob_flag) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z + zb;
+    if (x >= g.nx || y >= g.ny) return;
+    const int64_t i = gidx(g, x, y, z);
+    const int gz = z + g.gz0;
+    T nu = fu[i], nv = fv[i], nw = fw[i], nd = fd[i];
+    const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
+    if (interior) {
+        const uint32_t fl = flags[i];
+        const T four = (T)4, two = (T)2;
+        bool oob = false;
+        const T u_c = U[i], u_xp = U[i + 1], v_c = V[i], v_yp = V[i + g.sy], w_c = W[i], w_zp = W[i + g.sz];
+        if (fl & FL_SELF_FLUID) {
+            const T u_ym = U[i - g.sy], u_xp_ym = U[i + 1 - g.sy], u_zm = U[i - g.sz], u_xp_zm = U[i + 1 - g.sz];
+            const T v_xm = V[i - 1], v_xm_yp = V[i - 1 + g.sy], v_zm = V[i - g.sz], v_yp_zm = V[i + g.sy - g.sz];
+            const T w_xm = W[i - 1], w_xm_zp = W[i - 1 + g.sz], w_ym = W[i - g.sy], w_ym_zp = W[i - g.sy + g.sz];
+            // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
+            nu = maccormack_one(g, qu, fu, x, y, gz, u_c, (v_c + v_xm + v_yp + v_xm_yp) / four,
+                                (w_c + w_xm + w_zp + w_xm_zp) / four, t_step, qu[i], nu, oob);
+            nv = maccormack_one(g, qv, fv, x, y, gz, (u_c + u_ym + u_xp + u_xp_ym) / four, v_c,
+                                (w_c + w_ym + w_zp + w_ym_zp) / four, t_step, qv[i], nv, oob);
+            nw = maccormack_one(g, qw, fw, x, y, gz, (u_c + u_zm + u_xp + u_xp_zm) / four,
+                                (v_c + v_zm + v_yp + v_yp_zm) / four, w_c, t_step, qw[i], nw, oob);
+        }
+        if (!(fl & FL_SELF_OBJECT))
+            nd = maccormack_one(g, qd, fd, x, y, gz, (u_c + u_xp) / two, (v_c + v_yp) / two, (w_c + w_zp) / two, t_step,
+                                qd[i], nd, oob);
+        if (oob) *oob_flag = 1;
+    }
+    mu[i] = nu; mv[i] = nv; mw[i] = nw; md[i] = nd;
+    if (cu) { cu[i] = nu; cv[i] = nv; cw[i] = nw; }
+}
+
 // Reflection about the projected field (Zehnder et al. 2018, Alg. 1):
 // out = 2*proj - tilde for the three velocity components.
 template <typename T>

@@ -81,6 +81,15 @@ enum {
     FS_ADVECT_DIRECT = 1     /* every tap a global load                                            */
 };
 
+/* advection scheme */
+enum {
+    FS_ADVECTION_SEMI_LAGRANGE = 0, /* main.cpp:256-291                                          */
+    FS_ADVECTION_MACCORMACK = 1     /* semi-Lagrange forward + the backward pass, correction and
+                                       limiter of 3_fluid/FluidSim.cpp:217-389 carried over to 3D
+                                       (not in the 3D reference); the density is then carried by the
+                                       plain face average of the carrying velocity                  */
+};
+
 /* step variants of fs3d_advance */
 enum {
     FS_STEP_REFERENCE = 0,   /* project, then self-advect: FluidSim::update (main.cpp:102-130)   */
@@ -101,6 +110,9 @@ typedef struct fs3d_config {
                              (exercises the multi-GPU slab path inside one process)            */
     int32_t sweep_kernel; /* FS_SWEEP_*                                                           */
     int32_t advect_kernel;/* FS_ADVECT_*                                                          */
+    int32_t advection;    /* FS_ADVECTION_*, the scheme of fs3d_advance (fs3d_update and
+                             fs3d_semi_lagrange stay the reference's semi-Lagrange)                */
+    int32_t reserved;
     double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
     double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
     double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */

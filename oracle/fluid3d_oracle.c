@@ -436,6 +436,67 @@ void o3_advect(const O3 *o, real t_step, const real *qu, const real *qv, const r
     }
 }
 
+/* The eight taps of sample() (main.cpp:400-407) for a trace over t_step, as safe_sample returns them;
+ * lo/hi receive their minimum and maximum. */
+static inline void sample_bounds(const O3 *o, real x, real y, real z, real dx, real dy, real dz, real t_step,
+                                 const real *samples, real *lo, real *hi) {
+    const real nx = x - dx * t_step, ny = y - dy * t_step, nz = z - dz * t_step;
+    const real bx = floor(nx), tx = bx + 1, by = floor(ny), ty = by + 1, bz = floor(nz), tz = bz + 1;
+    const int xs[2] = {(int)bx, (int)tx}, ys[2] = {(int)by, (int)ty}, zs[2] = {(int)bz, (int)tz};
+    static const int order[8][3] = {{0,0,0},{1,0,0},{0,1,0},{0,0,1},{1,1,0},{1,0,1},{0,1,1},{1,1,1}};
+    real mn = 0, mx = 0;
+    for (int k = 0; k < 8; ++k) {
+        const real s = safe_sample(o, samples, xs[order[k][0]], ys[order[k][1]], zs[order[k][2]], 0);
+        if (k == 0) { mn = s; mx = s; }
+        mn = s < mn ? s : mn;
+        mx = s > mx ? s : mx;
+    }
+    *lo = mn; *hi = mx;
+}
+
+/* MacCormack correction and limiter: the scheme of 3_fluid/FluidSim.cpp:217-389 (MacCormackUpdate,
+ * MacCormackClamp) carried over to the 3D sampler of main.cpp.  Not in the 3D reference.
+ * Given q, the carrying velocity (U,V,W) and the forward result f = o3_advect(q; U,V,W, t_step, mode 0):
+ *   b = f traced backwards (t_step -> -t_step, FluidSim.cpp:224-236)
+ *   m = f + 0.5 * (q - b)                                  (FluidSim.cpp:238-262)
+ *   m = f where m leaves [min, max] of the eight taps of q that the forward trace read (FluidSim.cpp:264-389)
+ * on the locations o3_advect advects; all others keep f (= q there). */
+void o3_maccormack(const O3 *o, real t_step, const real *qu, const real *qv, const real *qw, const real *qd,
+                   const real *U, const real *V, const real *W, const real *fu, const real *fv, const real *fw,
+                   const real *fd, real *mu, real *mv, real *mw, real *md) {
+    const real two = R(2.0), half = R(0.5);
+    const int64_t n = o3_n(o);
+    memcpy(mu, fu, n * sizeof(real)); memcpy(mv, fv, n * sizeof(real));
+    memcpy(mw, fw, n * sizeof(real)); memcpy(md, fd, n * sizeof(real));
+    const real *q[3] = {qu, qv, qw}, *f[3] = {fu, fv, fw};
+    real *m[3] = {mu, mv, mw};
+    FOR_INTERIOR(o) {
+        const int64_t i = IDX(o, x, y, z);
+        if (o->s[i] == CELL_FLUID) {
+            for (int c = 0; c < 3; ++c) {
+                real dx, dy, dz, lo, hi;
+                face_velocity(o, U, V, W, x, y, z, c, &dx, &dy, &dz);
+                const real b = sample(o, (real)x, (real)y, (real)z, dx, dy, dz, -t_step, f[c]);
+                real v = f[c][i] + half * (q[c][i] - b);
+                sample_bounds(o, (real)x, (real)y, (real)z, dx, dy, dz, t_step, q[c], &lo, &hi);
+                if (v < lo || v > hi) v = f[c][i];
+                m[c][i] = v;
+            }
+        }
+        if (o->s[i] != CELL_OBJECT) {
+            const real uc = (U[i] + U[IDX(o, x + 1, y, z)]) / two;
+            const real vc = (V[i] + V[IDX(o, x, y + 1, z)]) / two;
+            const real wc = (W[i] + W[IDX(o, x, y, z + 1)]) / two;
+            real lo, hi;
+            const real b = sample(o, (real)x, (real)y, (real)z, uc, vc, wc, -t_step, fd);
+            real v = fd[i] + half * (qd[i] - b);
+            sample_bounds(o, (real)x, (real)y, (real)z, uc, vc, wc, t_step, qd, &lo, &hi);
+            if (v < lo || v > hi) v = fd[i];
+            md[i] = v;
+        }
+    }
+}
+
 /* Reflection of the unprojected field about the projected one (Zehnder et
  * al. 2018, Alg. 1): out = 2*proj - tilde, on every element. */
 void o3_reflect(int64_t n, const real *proj, const real *tilde, real *out) {

@@ -61,6 +61,7 @@ def _lib(dtype):
     lib.o3_residual_l2.argtypes = [P]
     lib.o3_advect.argtypes = [P, real] + [P] * 11 + [C.c_int]
     lib.o3_reflect.argtypes = [C.c_int64, P, P, P]
+    lib.o3_maccormack.argtypes = [P, real] + [P] * 15
     lib.o3_buoyancy.argtypes = [P, real]
     lib.o3_project_rb.restype = C.c_int
     lib.o3_project_rb.argtypes = [P, real, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -191,6 +192,17 @@ class Oracle3D:
         out = [np.empty_like(q[0]) for _ in range(4)]
         self.lib.o3_advect(self.h, dt, *[_ptr(a) for a in q], *[_ptr(a) for a in vel],
                            *[_ptr(a) for a in out], density_mode)
+        return out
+
+    def maccormack(self, dt, q, vel, f):
+        """MacCormack correction + limiter: q, f = (u,v,w,d) before and after the forward advection over dt
+        along vel = (U,V,W); returns the four corrected arrays."""
+        q = [np.ascontiguousarray(a, dtype=self.dtype) for a in q]
+        vel = [np.ascontiguousarray(a, dtype=self.dtype) for a in vel]
+        f = [np.ascontiguousarray(a, dtype=self.dtype) for a in f]
+        out = [np.empty_like(q[0]) for _ in range(4)]
+        self.lib.o3_maccormack(self.h, dt, *[_ptr(a) for a in q], *[_ptr(a) for a in vel], *[_ptr(a) for a in f],
+                               *[_ptr(a) for a in out])
         return out
 
     def reflect(self, proj, tilde):

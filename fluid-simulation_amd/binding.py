@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libfluidsim_amd.so")
 FS_OK = 0
 F32, F64 = 0, 1
 CELL_FLUID, CELL_OBJECT, CELL_STATIC_FLUID = 0, 1, 2
-FIELD_U, FIELD_V, FIELD_W, FIELD_DENSITY, FIELD_DIVERGENCE = range(5)
+FIELD_U, FIELD_V, FIELD_W, FIELD_DENSITY, FIELD_DIVERGENCE, FIELD_VORTICITY = range(6)
 ORDER_RED_BLACK, ORDER_LEXICOGRAPHIC = 0, 1
 STOP_FIXED, STOP_L1_CHANGE, STOP_L2_RESIDUAL = 0, 1, 2
 STEP_REFERENCE, STEP_REFLECTION = 0, 1
@@ -40,7 +40,8 @@ EXPORTS = [
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
-    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fsamd_comm_unique_id", "fsamd_comm_selftest",
+    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
+    "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fsamd_comm_unique_id", "fsamd_comm_selftest",
     "fs3d_create_slab", "fs3d_slab_range",
     "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
     "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
@@ -61,6 +62,11 @@ class Stats(C.Structure):
         ("step", C.c_int64), ("time", C.c_double), ("sweeps", C.c_int32), ("sweeps_step", C.c_int32),
         ("metric", C.c_double), ("ms_project", C.c_double), ("ms_advect", C.c_double), ("ms_step", C.c_double),
     ]
+
+
+class Diag(C.Structure):
+    _fields_ = [("kinetic_energy", C.c_double), ("max_speed", C.c_double), ("density_sum", C.c_double),
+                ("enstrophy", C.c_double)]
 
 
 class FluidSimError(RuntimeError):
@@ -114,6 +120,10 @@ def load_library(path=None):
         "fs3d_advance": (I, [P, D]),
         "fs3d_get_stats": (I, [P, C.POINTER(Stats)]),
         "fs3d_synchronize": (I, [P]),
+        "fs3d_diagnostics": (I, [P, C.POINTER(Diag)]),
+        "fs3d_get_density_downsampled": (I, [P, I, P, C.c_size_t]),
+        "fs3d_save": (I, [P, C.c_char_p]),
+        "fs3d_load": (I, [P, C.c_char_p]),
         "fsamd_comm_unique_id": (I, [P]),
         "fsamd_comm_selftest": (I, [I]),
         "fs3d_create_slab": (I, [I, I, I, C.POINTER(Config), I, I, P, C.POINTER(P)]),
@@ -227,6 +237,28 @@ class FluidSim3D:
         if a.size != self.count:
             raise ValueError("field size mismatch")
         self._chk(self.lib.fs3d_set_field(self.h, which, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def vorticity(self):
+        """|curl u| with the stencil of computeVorticity (3_fluid/FluidSim.h:220-229)."""
+        return self.get_field(FIELD_VORTICITY)
+
+    def diagnostics(self):
+        d = Diag()
+        self._chk(self.lib.fs3d_diagnostics(self.h, C.byref(d)))
+        return d
+
+    def downsample_density(self, factor):
+        """Density averaged over blocks of factor^3 cells (of the owned planes)."""
+        shape = tuple((n + factor - 1) // factor for n in self.shape)
+        out = np.empty(shape, dtype=self.dtype)
+        self._chk(self.lib.fs3d_get_density_downsampled(self.h, factor, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def save(self, path):
+        self._chk(self.lib.fs3d_save(self.h, os.fsencode(path)))
+
+    def load(self, path):
+        self._chk(self.lib.fs3d_load(self.h, os.fsencode(path)))
 
     def get_field_plane(self, which, z):
         out = np.empty((self.ny, self.nx), dtype=self.dtype)

@@ -24,8 +24,13 @@
 #include "fs_common.hpp"
 #include "fs_kernels3d.hpp"
 #include "fs_sweep_fused.hpp"
+#include <cstdio>
+#include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 #include "fs_sweep_rows.hpp"
 #include "fs_advect_tiled.hpp"
+#include "fs_diag3d.hpp"
 
 using namespace fsamd;
 
@@ -756,6 +761,68 @@ int step(fs3d_sim* s, double dt) {
     return FS_OK;
 }
 
+void owned_range(const fs3d_sim* s, int* z0, int* z1);
+
+// ---- diagnostics -------------------------------------------------------------
+template <typename T>
+int vorticity(fs3d_sim* s, bool store, double* enstrophy) {
+    FS_TRY(prepare(s));
+    for (int k = 0; k < s->nlocal; ++k) {
+        Part& p = s->parts[k];
+        const int zb = p.H, ze = p.H + p.own_planes();
+        hipLaunchKernelGGL(k_vorticity<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv, 0),
+                           F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), zb, ze, store ? (T*)p.tmp[0] : (T*)nullptr, p.partials);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
+    }
+    SIM_HIP(hipGetLastError());
+    return finish_reduction(s, enstrophy, nullptr);
+}
+
+template <typename T>
+int energy_mass(fs3d_sim* s, int what, double* sum, double* mx) {
+    FS_TRY(prepare(s, HALO_ALL));
+    for (int k = 0; k < s->nlocal; ++k) {
+        Part& p = s->parts[k];
+        if (p.ze > p.zb)
+            hipLaunchKernelGGL(k_energy_mass<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv, 0),
+                               F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), F<T>(p, s->curd, 3), p.flags, p.zb, p.ze, what,
+                               p.partials);
+        else
+            SIM_HIP(hipMemsetAsync(p.partials, 0, sizeof(double) * 2 * kReduceBlocks, s->stream));
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
+    }
+    SIM_HIP(hipGetLastError());
+    return finish_reduction(s, sum, mx);
+}
+
+template <typename T>
+int downsample(fs3d_sim* s, int f, void* host, size_t count) {
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const int mx = div_up(s->nx, f), my = div_up(s->ny, f);
+    for (Part& p : s->parts)
+        if (p.z0 % f != 0) return set_err(s, FS_EINVAL, "every slab must start on a multiple of the factor");
+    size_t total = 0;
+    for (Part& p : s->parts) total += (size_t)div_up(p.own_planes(), f) * my * mx;
+    if (count != total) return set_err(s, FS_EINVAL, "count must be the number of blocks of the owned planes");
+    T* dev = nullptr;
+    SIM_HIP(hipMalloc((void**)&dev, total * sizeof(T)));
+    size_t off = 0;
+    for (Part& p : s->parts) {
+        const int mz = div_up(p.own_planes(), f);
+        dim3 b(64, 4, 1), g(div_up(mx, 64), div_up(my, 4), mz);
+        hipLaunchKernelGGL(k_downsample<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curd, 3), f, p.H, p.H + p.own_planes(), mx, my,
+                           dev + off);
+        off += (size_t)mz * my * mx;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, total * sizeof(T), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(dev);
+    SIM_HIP(e);
+    return FS_OK;
+}
+
 #define DISPATCH(s, fn, ...) ((s)->cfg.dtype == FS_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
 // ---- host <-> device field access -----------------------------------------
@@ -1132,11 +1199,12 @@ int fs3d_set_field(fs3d_sim* s, int which, const void* host, size_t count) {
 
 int fs3d_get_field(fs3d_sim* s, int which, void* host, size_t count) {
     SIM_GUARD(s);
-    if (!host || which < FS_FIELD_U || which > FS_FIELD_DIVERGENCE) return set_err(s, FS_EINVAL, "bad field or null pointer");
+    if (!host || which < FS_FIELD_U || which > FS_FIELD_VORTICITY) return set_err(s, FS_EINVAL, "bad field or null pointer");
     int z0, z1;
     owned_range(s, &z0, &z1);
     const size_t plane = (size_t)s->nx * s->ny;
     if (count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
+    if (which == FS_FIELD_VORTICITY) FS_TRY(DISPATCH(s, vorticity, s, true, nullptr));
     if (which == FS_FIELD_DIVERGENCE) {
         FS_TRY(prepare(s));
         for (Part& p : s->parts) SIM_HIP(hipMemsetAsync(p.tmp[0], 0, p.n * s->esz, s->stream));
@@ -1321,6 +1389,103 @@ int fs3d_update(fs3d_sim* s, double t_step) {
 int fs3d_advance(fs3d_sim* s, double dt) {
     SIM_GUARD(s);
     return DISPATCH(s, step, s, dt);
+}
+
+int fs3d_diagnostics(fs3d_sim* s, fs3d_diag* out) {
+    SIM_GUARD(s);
+    if (!out) return set_err(s, FS_EINVAL, "null pointer");
+    FS_TRY(DISPATCH(s, energy_mass, s, 0, &out->kinetic_energy, &out->max_speed));
+    FS_TRY(DISPATCH(s, energy_mass, s, 1, &out->density_sum, nullptr));
+    return DISPATCH(s, vorticity, s, false, &out->enstrophy);
+}
+
+int fs3d_get_density_downsampled(fs3d_sim* s, int factor, void* host, size_t count) {
+    SIM_GUARD(s);
+    if (!host || factor < 1) return set_err(s, FS_EINVAL, "null pointer or factor < 1");
+    return DISPATCH(s, downsample, s, factor, host, count);
+}
+
+// Restart file: a 64-byte header, then the cell types (1 byte per cell) and u, v, w, density of the whole
+// grid, x fastest.  Every rank writes (reads) its owned planes at their place in the one file.
+namespace {
+struct RestartHeader {
+    char magic[8];            // "FSAMD3D"
+    int32_t version, dtype, nx, ny, nz, hint0, hint1, pad;
+    int64_t step;
+    double time;
+    int64_t reserved;
+};
+static_assert(sizeof(RestartHeader) == 64, "restart header is 64 bytes");
+
+int file_io(fs3d_sim* s, int fd, bool write, void* buf, size_t bytes, off_t at) {
+    char* c = (char*)buf;
+    while (bytes > 0) {
+        const ssize_t n = write ? pwrite(fd, c, bytes, at) : pread(fd, c, bytes, at);
+        if (n <= 0) return set_err(s, FS_ESTATE, write ? "short write to the restart file" : "short read from the restart file");
+        c += n; at += n; bytes -= (size_t)n;
+    }
+    return FS_OK;
+}
+}  // namespace
+
+int fs3d_save(fs3d_sim* s, const char* path) {
+    SIM_GUARD(s);
+    if (!path) return set_err(s, FS_EINVAL, "null path");
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny, cells = plane * s->nz, mine = plane * (size_t)(z1 - z0);
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) return set_err(s, FS_ESTATE, "cannot open the restart file for writing");
+    int rc = FS_OK;
+    if (s->rank == 0) {
+        RestartHeader h{};
+        memcpy(h.magic, "FSAMD3D", 8);
+        h.version = 1; h.dtype = s->cfg.dtype; h.nx = s->nx; h.ny = s->ny; h.nz = s->nz;
+        h.hint0 = s->sweep_hint[0]; h.hint1 = s->sweep_hint[1];
+        h.step = s->stats.step; h.time = s->stats.time;
+        rc = file_io(s, fd, true, &h, sizeof(h), 0);
+    }
+    std::vector<char> buf(mine * s->esz);
+    if (rc == FS_OK) rc = fs3d_get_cell_types(s, (uint8_t*)buf.data(), mine);
+    if (rc == FS_OK) rc = file_io(s, fd, true, buf.data(), mine, (off_t)(sizeof(RestartHeader) + plane * z0));
+    for (int k = 0; k < 4 && rc == FS_OK; ++k) {
+        rc = fs3d_get_field(s, k, buf.data(), mine);
+        if (rc == FS_OK)
+            rc = file_io(s, fd, true, buf.data(), mine * s->esz,
+                         (off_t)(sizeof(RestartHeader) + cells + ((size_t)k * cells + plane * z0) * s->esz));
+    }
+    if (close(fd) != 0 && rc == FS_OK) rc = set_err(s, FS_ESTATE, "closing the restart file failed");
+    return rc;
+}
+
+int fs3d_load(fs3d_sim* s, const char* path) {
+    SIM_GUARD(s);
+    if (!path) return set_err(s, FS_EINVAL, "null path");
+    int z0, z1;
+    owned_range(s, &z0, &z1);
+    const size_t plane = (size_t)s->nx * s->ny, cells = plane * s->nz, mine = plane * (size_t)(z1 - z0);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return set_err(s, FS_ESTATE, "cannot open the restart file");
+    RestartHeader h{};
+    int rc = file_io(s, fd, false, &h, sizeof(h), 0);
+    if (rc == FS_OK && (memcmp(h.magic, "FSAMD3D", 8) != 0 || h.version != 1))
+        rc = set_err(s, FS_EINVAL, "not a restart file of this library");
+    if (rc == FS_OK && (h.nx != s->nx || h.ny != s->ny || h.nz != s->nz || h.dtype != s->cfg.dtype))
+        rc = set_err(s, FS_EINVAL, "the restart file has another grid size or element type");
+    std::vector<char> buf(mine * s->esz);
+    if (rc == FS_OK) rc = file_io(s, fd, false, buf.data(), mine, (off_t)(sizeof(RestartHeader) + plane * z0));
+    if (rc == FS_OK) rc = fs3d_set_cell_types(s, (const uint8_t*)buf.data(), mine);
+    for (int k = 0; k < 4 && rc == FS_OK; ++k) {
+        rc = file_io(s, fd, false, buf.data(), mine * s->esz,
+                     (off_t)(sizeof(RestartHeader) + cells + ((size_t)k * cells + plane * z0) * s->esz));
+        if (rc == FS_OK) rc = fs3d_set_field(s, k, buf.data(), mine);
+    }
+    (void)close(fd);
+    if (rc != FS_OK) return rc;
+    s->sweep_hint[0] = std::max(1, h.hint0); s->sweep_hint[1] = std::max(1, h.hint1);
+    s->stats = fs3d_stats{};
+    s->stats.step = h.step; s->stats.time = h.time;
+    return FS_OK;
 }
 
 int fs3d_get_stats(fs3d_sim* s, fs3d_stats* out) {

@@ -47,7 +47,8 @@ enum { FS_F32 = 0, FS_F64 = 1 };
 enum { FS_CELL_FLUID = 0, FS_CELL_OBJECT = 1, FS_CELL_STATIC_FLUID = 2 };
 
 /* field selectors for fs3d_set_field / fs3d_get_field */
-enum { FS_FIELD_U = 0, FS_FIELD_V = 1, FS_FIELD_W = 2, FS_FIELD_DENSITY = 3, FS_FIELD_DIVERGENCE = 4 };
+enum { FS_FIELD_U = 0, FS_FIELD_V = 1, FS_FIELD_W = 2, FS_FIELD_DENSITY = 3, FS_FIELD_DIVERGENCE = 4,
+       FS_FIELD_VORTICITY = 5 /* |curl u|, the 3D form of computeVorticity, 3_fluid/FluidSim.h:220-229 */ };
 
 /* visiting order of the projection sweep */
 enum {
@@ -209,6 +210,30 @@ int fs3d_get_stats(fs3d_sim *sim, fs3d_stats *out);
  * this call, and any projection that evaluates its stopping metric, returns
  * FS_ESTATE for it, until fs3d_reset.                                        */
 int fs3d_synchronize(fs3d_sim *sim);
+
+/* Diagnostics of the current state (the reference prints none; they are what shows
+ * what the reflection preserves).  Cell-centred velocities as in
+ * draw_velocity_field (main.cpp:138-142), interior cells that are not Object;
+ * enstrophy with the stencil of computeVorticity (3_fluid/FluidSim.h:220-229).    */
+typedef struct fs3d_diag {
+    double kinetic_energy;   /* sum (u^2 + v^2 + w^2) / 2                                       */
+    double max_speed;        /* largest cell-centred velocity norm                              */
+    double density_sum;      /* sum of the density                                              */
+    double enstrophy;        /* sum |curl u|^2                                                  */
+} fs3d_diag;
+int fs3d_diagnostics(fs3d_sim *sim, fs3d_diag *out);
+/* The density averaged over blocks of factor^3 cells, x fastest, ceil(n/factor)
+ * blocks per axis: the per-frame fetch for a renderer (Renderer.h:205-241 uploads
+ * the whole grid) when the full field is too large to move every frame.  On a slab
+ * handle the owned planes, whose first plane must be a multiple of factor.        */
+int fs3d_get_density_downsampled(fs3d_sim *sim, int factor, void *host, size_t count);
+/* Restart files (the reference has none).  fs3d_save writes the grid size, element
+ * type, step, time, the cell types and u, v, w, density of the whole grid to `path`
+ * (every rank of a slab decomposition writes its planes into the same file);
+ * fs3d_load reads them back into a handle of the same size and element type.  A run
+ * continued from a file repeats the uninterrupted run bit for bit.                 */
+int fs3d_save(fs3d_sim *sim, const char *path);
+int fs3d_load(fs3d_sim *sim, const char *path);
 
 /* z-slab decomposition over the GPUs of one node (no counterpart in the
  * reference, which is single-process) ------------------------------------- */

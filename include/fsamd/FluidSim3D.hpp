@@ -99,6 +99,15 @@ public:
         check(fs3d_get_field(sim_, which, out.data(), out.size()));
     }
     fs3d_stats stats() { fs3d_stats st; check(fs3d_get_stats(sim_, &st)); return st; }
+    fs3d_diag diagnostics() { fs3d_diag d; check(fs3d_diagnostics(sim_, &d)); return d; }
+    // the density averaged over factor^3 blocks, for a renderer that cannot take the whole grid per frame
+    void get_density_downsampled(int factor, std::vector<float>& out) {
+        auto blocks = [factor](int n) { return (size_t)((n + factor - 1) / factor); };
+        out.resize(blocks(nx_) * blocks(ny_) * blocks(nz_));
+        check(fs3d_get_density_downsampled(sim_, factor, out.data(), out.size()));
+    }
+    void save(const std::string& path) { check(fs3d_save(sim_, path.c_str())); }
+    void load(const std::string& path) { check(fs3d_load(sim_, path.c_str())); }
     void reset() { check(fs3d_reset(sim_)); }
     void advance(double dt) { check(fs3d_advance(sim_, dt)); }
 

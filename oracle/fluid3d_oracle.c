@@ -497,6 +497,67 @@ void o3_maccormack(const O3 *o, real t_step, const real *qu, const real *qv, con
     }
 }
 
+/* Vorticity magnitude: the central differences of 3_fluid/FluidSim.h:220-229 (face values two cells
+ * apart, times 0.5, cells 2..n-3) for the three components of the curl; out is zero elsewhere.
+ * Returns sum |curl|^2 accumulated in double. */
+double o3_vorticity(const O3 *o, real *out) {
+    const real half = R(0.5);
+    double ens = 0;
+    memset(out, 0, o3_n(o) * sizeof(real));
+    for (int z = 2; z < o->nz - 2; ++z)
+        for (int y = 2; y < o->ny - 2; ++y)
+            for (int x = 2; x < o->nx - 2; ++x) {
+                const real dwdy = (o->w[IDX(o, x, y + 1, z)] - o->w[IDX(o, x, y - 1, z)]) * half;
+                const real dvdz = (o->v[IDX(o, x, y, z + 1)] - o->v[IDX(o, x, y, z - 1)]) * half;
+                const real dudz = (o->u[IDX(o, x, y, z + 1)] - o->u[IDX(o, x, y, z - 1)]) * half;
+                const real dwdx = (o->w[IDX(o, x + 1, y, z)] - o->w[IDX(o, x - 1, y, z)]) * half;
+                const real dvdx = (o->v[IDX(o, x + 1, y, z)] - o->v[IDX(o, x - 1, y, z)]) * half;
+                const real dudy = (o->u[IDX(o, x, y + 1, z)] - o->u[IDX(o, x, y - 1, z)]) * half;
+                const real cx = dwdy - dvdz, cy = dudz - dwdx, cz = dvdx - dudy;
+                const double e = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+                out[IDX(o, x, y, z)] = (real)sqrt(e);
+                ens += e;
+            }
+    return ens;
+}
+
+/* Diagnostics over the interior cells that are not Object, with the cell-centred velocity of
+ * draw_velocity_field (main.cpp:138-142): out[0] = sum of (u^2+v^2+w^2)/2, out[1] = largest norm,
+ * out[2] = sum of the density, all accumulated in double. */
+void o3_diagnostics(const O3 *o, double out[3]) {
+    const real two = R(2.0);
+    double ke = 0, mx = 0, mass = 0;
+    FOR_INTERIOR(o) {
+        const int64_t i = IDX(o, x, y, z);
+        if (o->s[i] == CELL_OBJECT) continue;
+        const real u = (o->u[i] + o->u[IDX(o, x + 1, y, z)]) / two;
+        const real v = (o->v[i] + o->v[IDX(o, x, y + 1, z)]) / two;
+        const real w = (o->w[i] + o->w[IDX(o, x, y, z + 1)]) / two;
+        const double n2 = (double)u * u + (double)v * v + (double)w * w;
+        ke += 0.5 * n2;
+        const double nrm = sqrt(n2);
+        mx = nrm > mx ? nrm : mx;
+        mass += (double)o->d[i];
+    }
+    out[0] = ke; out[1] = mx; out[2] = mass;
+}
+
+/* Density averaged over blocks of f*f*f cells (the last block of an axis may be smaller), summed in
+ * double in x-fastest order; what a renderer that cannot take the full grid per frame fetches. */
+void o3_downsample_density(const O3 *o, int f, real *out) {
+    const int mx = (o->nx + f - 1) / f, my = (o->ny + f - 1) / f, mz = (o->nz + f - 1) / f;
+    for (int bz = 0; bz < mz; ++bz)
+        for (int by = 0; by < my; ++by)
+            for (int bx = 0; bx < mx; ++bx) {
+                double sum = 0;
+                int cnt = 0;
+                for (int z = bz * f; z < (bz + 1) * f && z < o->nz; ++z)
+                    for (int y = by * f; y < (by + 1) * f && y < o->ny; ++y)
+                        for (int x = bx * f; x < (bx + 1) * f && x < o->nx; ++x) { sum += (double)o->d[IDX(o, x, y, z)]; ++cnt; }
+                out[((int64_t)bz * my + by) * mx + bx] = (real)(sum / cnt);
+            }
+}
+
 /* Reflection of the unprojected field about the projected one (Zehnder et
  * al. 2018, Alg. 1): out = 2*proj - tilde, on every element. */
 void o3_reflect(int64_t n, const real *proj, const real *tilde, real *out) {

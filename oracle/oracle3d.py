@@ -62,6 +62,10 @@ def _lib(dtype):
     lib.o3_advect.argtypes = [P, real] + [P] * 11 + [C.c_int]
     lib.o3_reflect.argtypes = [C.c_int64, P, P, P]
     lib.o3_maccormack.argtypes = [P, real] + [P] * 15
+    lib.o3_vorticity.argtypes = [P, P]
+    lib.o3_vorticity.restype = C.c_double
+    lib.o3_diagnostics.argtypes = [P, C.POINTER(C.c_double)]
+    lib.o3_downsample_density.argtypes = [P, C.c_int, P]
     lib.o3_buoyancy.argtypes = [P, real]
     lib.o3_project_rb.restype = C.c_int
     lib.o3_project_rb.argtypes = [P, real, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -203,6 +207,24 @@ class Oracle3D:
         out = [np.empty_like(q[0]) for _ in range(4)]
         self.lib.o3_maccormack(self.h, dt, *[_ptr(a) for a in q], *[_ptr(a) for a in vel], *[_ptr(a) for a in f],
                                *[_ptr(a) for a in out])
+        return out
+
+    def vorticity(self):
+        """(|curl u| field, sum of |curl u|^2)"""
+        out = np.empty((self.nz, self.ny, self.nx), dtype=self.dtype)
+        ens = self.lib.o3_vorticity(self.h, _ptr(out))
+        return out, float(ens)
+
+    def diagnostics(self):
+        """(kinetic energy, max speed, density sum)"""
+        d = (C.c_double * 3)()
+        self.lib.o3_diagnostics(self.h, d)
+        return d[0], d[1], d[2]
+
+    def downsample_density(self, f):
+        shape = tuple((n + f - 1) // f for n in (self.nz, self.ny, self.nx))
+        out = np.empty(shape, dtype=self.dtype)
+        self.lib.o3_downsample_density(self.h, f, _ptr(out))
         return out
 
     def reflect(self, proj, tilde):

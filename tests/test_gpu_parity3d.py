@@ -423,3 +423,20 @@ def test_maccormack_keeps_the_range_of_its_taps(fsamd):
     g.advance(1.0 / 30.0)
     d1 = g.get_field(3)
     assert d1.min() >= min(d0.min(), 0.0) and d1.max() <= max(d0.max(), 0.0)
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (24, 48, 24), (64, 40, 70), (130, 37, 9), (256, 30, 12), (20, 5, 6)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_stopping_metric_is_the_residual_of_the_field_left_behind(fsamd, shape, dtype):
+    # the metric a projection reports is the L2 residual of the field it leaves, as a separate call and
+    # the oracle compute it; tiles, z-chunks and masks of several shapes
+    nx, ny, nz = shape
+    o, g = make_pair(fsamd, nx, ny, nz, seed=51, scale=10.0, dtype=dtype, stop_mode=2, tol=0.0, max_iters=3, check_every=1)
+    sweeps, metric = g.project()
+    assert sweeps == 3
+    l2, mx = g.residual()
+    assert metric == pytest.approx(l2, rel=1e-12)
+    for _ in range(3):
+        o.rb_sweep()
+    assert_fields_equal(o, g, "uvw", what="check sweeps")
+    assert l2 == pytest.approx(o.residual_l2(), rel=1e-12)

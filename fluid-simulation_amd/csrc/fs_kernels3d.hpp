@@ -226,6 +226,8 @@ k_change_l1(Grid g, const T* __restrict__ au, const T* __restrict__ av, const T*
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0; }
 }
 
+template <typename T, int N> struct alignas(N * sizeof(T)) Vec { T e[N]; };
+
 // Sum of squared divergences and max |div| over the cells a visit can relax
 // (not Object, s > 0, and at least one face the visit may move: a StaticFluid
 // cell moves only its high faces, main.cpp:227-232), planes [zb, ze).
@@ -234,21 +236,64 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_div_sumsq(Grid g, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ w,
             const uint8_t* __restrict__ flags, int zb, int ze, double* __restrict__ part, T* __restrict__ div_out) {
-    const int64_t rows = (int64_t)(g.ny - 2) * (ze - zb);
+    // A job is a strip of kRows rows marched through kPlanes planes by one workgroup: the next row of v
+    // and the next plane of w that a cell reads are then read again by the same workgroup a moment later
+    // (round-robin rows made every v row and w plane come from HBM twice, 21 instead of 13 B per cell).
+    constexpr int kRows = 4, kPlanes = 16;
+    constexpr int kVec = 16 / (int)sizeof(T);
+    const bool wide = g.nx % kVec == 0;   // rows then start on 16-byte boundaries
+    const int ytiles = (g.ny - 2 + kRows - 1) / kRows, zchunks = (ze - zb + kPlanes - 1) / kPlanes;
     double s = 0, m = 0;
-    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int y = (int)(r % (g.ny - 2)) + 1, z = (int)(r / (g.ny - 2)) + zb;
-        const int64_t row = gidx(g, 0, y, z);
-        for (int x = threadIdx.x + 1; x < g.nx - 1; x += 256) {
-            const int64_t i = row + x;
-            const uint32_t fl = flags[i];
-            const T div = (u[i + 1] - u[i]) + (v[i + g.sy] - v[i]) + (w[i + g.sz] - w[i]);
-            if (div_out) div_out[i] = div;
-            const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
-            if (relaxes(fl) && movable) {
-                const double dv = (double)div;
-                s += dv * dv;
-                m = fmax(m, fabs(dv));
+    for (int64_t job = blockIdx.x; job < (int64_t)ytiles * zchunks; job += gridDim.x) {
+        const int y0 = 1 + (int)(job % ytiles) * kRows, z0 = zb + (int)(job / ytiles) * kPlanes;
+        const int yend = min(y0 + kRows, g.ny - 1);
+        for (int z = z0; z < min(z0 + kPlanes, ze); ++z) {
+            if (wide) {
+                // kVec cells per lane with 16-byte loads, the rows of the strip side by side; the high-x face
+                // of a lane's last cell is the next lane's first u, or a scalar load at the end of a wave
+                const int nvx = g.nx / kVec;
+                for (int idx = threadIdx.x; idx < nvx * (yend - y0); idx += 256) {
+                    const int ry = idx / nvx, x = (idx - ry * nvx) * kVec;
+                    const int64_t i = gidx(g, x, y0 + ry, z);
+                    const Vec<T, kVec> uu = *reinterpret_cast<const Vec<T, kVec>*>(u + i);
+                    const Vec<T, kVec> v0 = *reinterpret_cast<const Vec<T, kVec>*>(v + i);
+                    const Vec<T, kVec> v1 = *reinterpret_cast<const Vec<T, kVec>*>(v + i + g.sy);
+                    const Vec<T, kVec> w0 = *reinterpret_cast<const Vec<T, kVec>*>(w + i);
+                    const Vec<T, kVec> w1 = *reinterpret_cast<const Vec<T, kVec>*>(w + i + g.sz);
+                    const Vec<uint8_t, kVec> ff = *reinterpret_cast<const Vec<uint8_t, kVec>*>(flags + i);
+                    T un = __shfl_down(uu.e[0], 1, 64);
+                    if ((threadIdx.x & 63) == 63 && x + kVec < g.nx) un = u[i + kVec];
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) {
+                        const T u1 = k + 1 < kVec ? uu.e[k + 1 < kVec ? k + 1 : k] : un;
+                        const T div = (u1 - uu.e[k]) + (v1.e[k] - v0.e[k]) + (w1.e[k] - w0.e[k]);
+                        const bool interior = x + k >= 1 && x + k < g.nx - 1;
+                        if (div_out && interior) div_out[i + k] = div;
+                        const uint32_t fl = ff.e[k];
+                        const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
+                        if (interior && relaxes(fl) && movable) {
+                            const double dv = (double)div;
+                            s += dv * dv;
+                            m = fmax(m, fabs(dv));
+                        }
+                    }
+                }
+                continue;
+            }
+            for (int y = y0; y < yend; ++y) {
+                const int64_t row = gidx(g, 0, y, z);
+                for (int x = threadIdx.x + 1; x < g.nx - 1; x += 256) {
+                    const int64_t i = row + x;
+                    const uint32_t fl = flags[i];
+                    const T div = (u[i + 1] - u[i]) + (v[i + g.sy] - v[i]) + (w[i + g.sz] - w[i]);
+                    if (div_out) div_out[i] = div;
+                    const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
+                    if (relaxes(fl) && movable) {
+                        const double dv = (double)div;
+                        s += dv * dv;
+                        m = fmax(m, fabs(dv));
+                    }
+                }
             }
         }
     }

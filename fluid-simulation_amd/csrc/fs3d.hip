@@ -428,10 +428,10 @@ int launch_fused_sweep(fs3d_sim* s) {
 // launch follows the total number of (row, plane) steps, not the number of busy CUs, so the tile keeps
 // the most rows a workgroup can have (the smallest share of halo rows) and the z-chunking only has to
 // provide about one workgroup per CU.
-template <typename T, int NSEG>
+template <typename T, int NSEG, int CP>
 int launch_rows_sweep(fs3d_sim* s) {
-    using C = RowsCfg<T, NSEG>;
-    auto kern = k_rb_rows<T, NSEG>;
+    using C = RowsCfg<T, NSEG, CP>;
+    auto kern = k_rb_rows<T, NSEG, CP>;
     SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
@@ -452,10 +452,19 @@ int launch_rows_sweep(fs3d_sim* s) {
 template <typename T>
 int launch_one_pass_sweep(fs3d_sim* s) {
     if (s->nx % 2 == 0 && s->cfg.sweep_kernel == FS_SWEEP_FUSED) {
-        constexpr int kMaxSeg = sizeof(T) == 8 ? 2 : 4;   // LDS: 3 planes x 16 rows x 128*NSEG columns
-        if (s->nx <= 128) return launch_rows_sweep<T, 1>(s);
-        if (s->nx <= 256 || kMaxSeg == 2) return launch_rows_sweep<T, 2>(s);
-        return launch_rows_sweep<T, kMaxSeg>(s);
+        // A lane moves 16 bytes per access where that is free: 8-byte elements, or rows of 4-byte elements of
+        // at most 256 columns (104 instead of 113 us per sweep at 256^3).  At 512 columns the 16-byte form of
+        // the 4-byte kernel spills more registers than the 8-byte form (five planes of u and w per column
+        // against 128 registers) and runs 1.35 instead of 0.88 ms, so wide rows keep 8-byte accesses.
+        if constexpr (sizeof(T) == 8) {
+            if (s->nx <= 128) return launch_rows_sweep<T, 1, 1>(s);
+            return launch_rows_sweep<T, 2, 1>(s);
+        } else {
+        if (s->nx % 4 == 0 && s->nx <= 256) return launch_rows_sweep<T, 1, 2>(s);
+        if (s->nx <= 128) return launch_rows_sweep<T, 1, 1>(s);
+        if (s->nx <= 256) return launch_rows_sweep<T, 2, 1>(s);
+        return launch_rows_sweep<T, 4, 1>(s);
+        }
     }
     return launch_fused_sweep<T>(s);
 }

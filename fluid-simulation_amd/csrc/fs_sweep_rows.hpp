@@ -1,16 +1,19 @@
 // One full red-black sweep in one pass over HBM, register-resident variant
-// for even nx (the arrays are then 8-byte aligned per column pair).
+// for even nx (the arrays are then aligned per column pair).
 //
 // A workgroup is up to 16 waves; wave r owns row y0 + r of a tile that is
-// W = 128*NSEG columns wide, lane l owns the column pairs (2l, 2l+1) + 128*sg.
-// The wave marches along z.  For its two columns a lane keeps u and w of the
-// five planes in flight in registers: the two cells a w face touches lie in
-// the same column, so w never leaves the lane, and the u faces a cell shares
-// with its x neighbours live in the neighbouring lanes and move by wave
-// shuffles.  Only v, which couples rows and therefore waves, is staged in LDS
-// (three planes).  Global traffic is one 8-byte load and one 8-byte store per
-// lane, field and plane: every face is read once and written once per sweep
-// (25 B per cell instead of the 50 B of two half-sweep launches).
+// W = 128*CP*NSEG columns wide.  A lane owns CP adjacent column pairs in each of
+// the NSEG segments of the row: columns sg*128*CP + 2*CP*lane + 2*j + c
+// (pair j, column c of the pair), so that one load or store of a lane moves
+// 2*CP elements (16 bytes: CP = 2 for 4-byte elements when nx is a multiple
+// of 4, CP = 1 for 8-byte elements).  The wave marches along z.  For its
+// columns a lane keeps u and w of the five planes in flight in registers: the
+// two cells a w face touches lie in the same column, so w never leaves the
+// lane, and the u faces a cell shares with its x neighbours live in the next
+// pair of the lane or in the neighbouring lane and move by wave shuffles.
+// Only v, which couples rows and therefore waves, is staged in LDS (three
+// planes).  Every face is read once and written once per sweep (25 B per cell
+// instead of the 50 B of two half-sweep launches).
 //
 // Per step t the workgroup applies colour 0 to plane t and colour 1 to plane
 // t-2; a cell visit (advection-reflection/main.cpp:198-233) touches only the
@@ -26,31 +29,36 @@
 
 namespace fsamd {
 
-template <typename T> struct alignas(2 * sizeof(T)) Pair { T a, b; };
-
-template <typename T, int NSEG>
-struct RowPlane {            // what a lane holds of one z-plane
-    T u[NSEG][2];
-    T w[NSEG][2];
-    uint32_t f[NSEG];        // flag bytes of the two columns, column 1 in bits 8..15
+template <typename T, int NQ, int NSEG>
+struct RowPlane {            // what a lane holds of one z-plane: NQ = NSEG*CP column pairs
+    T u[NQ][2];
+    T w[NQ][2];
+    uint32_t f[NSEG];        // flag bytes of the lane's 2*CP columns of a segment, column k in bits 8k..8k+7
 };
 
-template <typename T, int NSEG>
+template <typename T, int NSEG, int CP>
 struct RowsCfg {
     static constexpr int RY = 16;           // most rows (waves) a workgroup can have
-    static constexpr int W = 128 * NSEG;
-    static constexpr int NPV = 3;   // v planes in LDS
+    static constexpr int SEGW = 128 * CP;   // columns of one segment
+    static constexpr int W = SEGW * NSEG;
+    static constexpr int NQ = NSEG * CP;
+    static constexpr int NPV = 3;           // v planes in LDS
     static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
 };
 
-template <typename T, int NSEG>
+template <typename T, int NSEG, int CP>
 __global__ void __launch_bounds__(1024)
 k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
           FusedRanges r, int ntx, int nty, int rows) {
-    using C = RowsCfg<T, NSEG>;
+    using C = RowsCfg<T, NSEG, CP>;
+    constexpr int NQ = C::NQ;
+    using VecT = Vec<T, 2 * CP>;
+    using VecF = Vec<uint8_t, 2 * CP>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][RY][W], rows de-interleaved: even columns, then odd
+    // [NPV][rows][W]; a row holds, per pair index q, the even columns of all lanes, then the odd ones:
+    // the active cells of a row all have the same x parity, so a wave reads consecutive words
+    T* sv = reinterpret_cast<T*>(lds_raw);
 
     const int lane = threadIdx.x, ry = threadIdx.y;
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Renumber them so that the
@@ -58,8 +66,8 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     // neighbour are then fetched from HBM once and served from that L2 the second time.  (Placement is a
     // speed matter only; any mapping gives the same result.)
     const int total = gridDim.x, lin = blockIdx.x;
-    const int xcd = lin & 7, q = total >> 3, rem = total & 7;
-    const int logical = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+    const int xcd = lin & 7, qq = total >> 3, rem = total & 7;
+    const int logical = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (lin >> 3);
     const int by = logical % nty, bx = (logical / nty) % ntx, bz = logical / (nty * ntx);
     const int xr0 = bx * (C::W - 4), yr0 = by * (rows - 4);   // tile origin; tiles overlap by 4
     const int y = yr0 + ry;
@@ -75,131 +83,182 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     const int s0b = max(r.s0b, c0 - 2), s0e = min(r.s0e, c1 + 1);
     const int lb = max(0, c0 - 2), le = min(g.nzl, c1 + 2);
 
-    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * lane;
-    bool col_in[NSEG], col_core[NSEG];
+    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * CP * lane;
+    bool seg_in[NSEG], pair_core[NQ];
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
-        const int x = xr0 + sg * 128 + 2 * lane;
-        col_in[sg] = row_in && x < g.nx;                       // nx is even: a pair is in or out as a whole
-        col_core[sg] = row_core && x >= cx_lo && x < cx_hi;   // the bounds are even: no pair straddles them
+        const int x = xr0 + sg * C::SEGW + 2 * CP * lane;
+        seg_in[sg] = row_in && x < g.nx;   // nx is a multiple of 2*CP: a lane's columns are in or out as a whole
+#pragma unroll
+        for (int j = 0; j < CP; ++j)       // the bounds are even: no pair straddles them
+            pair_core[sg * CP + j] = row_core && x + 2 * j >= cx_lo && x + 2 * j < cx_hi;
     }
 
-    RowPlane<T, NSEG> P0, P1, P2, P3, P4;
-    Pair<T> vst[NSEG];
+    RowPlane<T, NQ, NSEG> P0, P1, P2, P3, P4;
+    VecT vst[NSEG];
 
-    auto load_uf = [&](RowPlane<T, NSEG>& X, int p) {   // u, flags and the v staging registers of plane p
+    auto load_uf = [&](RowPlane<T, NQ, NSEG>& X, int p) {   // u, flags and the v staging registers of plane p
         const bool pin = p >= lb && p < le;
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
-            const bool in = pin && col_in[sg];
-            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * 128 : 0;
-            Pair<T> pu = {0, 0}, pv = {0, 0};
-            uint32_t pf = FL_SELF_OBJECT | (FL_SELF_OBJECT << 8);
+            const bool in = pin && seg_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
+            VecT pu, pv;
+            VecF pf;
+#pragma unroll
+            for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; pf.e[k] = (uint8_t)FL_SELF_OBJECT; }
             if (in) {
-                pu = *reinterpret_cast<const Pair<T>*>(ui + i);
-                pv = *reinterpret_cast<const Pair<T>*>(vi + i);
-                pf = *reinterpret_cast<const uint16_t*>(flags + i);
+                pu = *reinterpret_cast<const VecT*>(ui + i);
+                pv = *reinterpret_cast<const VecT*>(vi + i);
+                pf = *reinterpret_cast<const VecF*>(flags + i);
             }
-            X.u[sg][0] = pu.a; X.u[sg][1] = pu.b; X.f[sg] = pf; vst[sg] = pv;
+            uint32_t fw = 0;
+#pragma unroll
+            for (int k = 0; k < 2 * CP; ++k) fw |= (uint32_t)pf.e[k] << (8 * k);
+            X.f[sg] = fw;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { X.u[sg * CP + j][0] = pu.e[2 * j]; X.u[sg * CP + j][1] = pu.e[2 * j + 1]; }
+            vst[sg] = pv;
         }
     };
-    auto load_w = [&](RowPlane<T, NSEG>& X, int p) {
+    auto load_w = [&](RowPlane<T, NQ, NSEG>& X, int p) {
         const bool pin = p >= lb && p < le;
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
-            const bool in = pin && col_in[sg];
-            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * 128 : 0;
-            Pair<T> pw = {0, 0};
-            if (in) pw = *reinterpret_cast<const Pair<T>*>(wi + i);
-            X.w[sg][0] = pw.a; X.w[sg][1] = pw.b;
+            const bool in = pin && seg_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
+            VecT pw;
+#pragma unroll
+            for (int k = 0; k < 2 * CP; ++k) pw.e[k] = 0;
+            if (in) pw = *reinterpret_cast<const VecT*>(wi + i);
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { X.w[sg * CP + j][0] = pw.e[2 * j]; X.w[sg * CP + j][1] = pw.e[2 * j + 1]; }
         }
     };
     auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 3 * C::NPV) % C::NPV) * rows + row) * C::W; };
+    auto vpos = [&](int q, int c) { return (2 * q + c) * 64 + lane; };   // place of (pair q, column c) in a row
     auto stage_v = [&](int p) {   // v staging registers -> LDS, own row
         T* row = vrow(p, ry);
 #pragma unroll
-        for (int sg = 0; sg < NSEG; ++sg) {
-            row[sg * 128 + lane] = vst[sg].a;
-            row[sg * 128 + 64 + lane] = vst[sg].b;
-        }
+        for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+            for (int j = 0; j < CP; ++j) {
+                row[vpos(sg * CP + j, 0)] = vst[sg].e[2 * j];
+                row[vpos(sg * CP + j, 1)] = vst[sg].e[2 * j + 1];
+            }
     };
     // One colour on plane p.  X holds plane p, Y plane p+1 (for the high-z faces).
-    auto relax = [&](RowPlane<T, NSEG>& X, RowPlane<T, NSEG>& Y, int p, int colour) {
+    auto relax = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
         const int c = (colour + xr0 + y + p + g.gz0) & 1;   // the active column of every pair of this row
         T* v0row = vrow(p, ry);
         T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
         const bool row_ok = ry < rows - 1;
-        T send[NSEG];
+        T send[NQ];
         if (c == 0) {
 #pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) {
-                const uint32_t fl = X.f[sg] & 0xffu;
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t fl = (X.f[q / CP] >> (16 * (q % CP))) & 0xffu;
                 const bool ok = row_ok && relaxes(fl);
-                const int a = sg * 128 + lane;
-                const T u0 = X.u[sg][0], u1 = X.u[sg][1];
+                const int a = vpos(q, 0);
+                const T u0 = X.u[q][0], u1 = X.u[q][1];
                 const T v0 = v0row[a], v1 = v1row[a];
-                const T w0 = X.w[sg][0], w1 = Y.w[sg][0];
+                const T w0 = X.w[q][0], w1 = Y.w[q][0];
                 const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
                 T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
                 if (omega != (T)1) dd = omega * dd;
                 const bool self = fl & FL_SELF_FLUID;
-                if (ok && (fl & FL_XM) && self) X.u[sg][0] = u0 + dd;
-                if (ok && (fl & FL_XP)) X.u[sg][1] = u1 - dd;
+                if (ok && (fl & FL_XM) && self) X.u[q][0] = u0 + dd;
+                if (ok && (fl & FL_XP)) X.u[q][1] = u1 - dd;
                 if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
                 if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
-                if (ok && (fl & FL_ZM) && self) X.w[sg][0] = w0 + dd;
-                if (ok && (fl & FL_ZP)) Y.w[sg][0] = w1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[q][0] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[q][0] = w1 - dd;
             }
         } else {
 #pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) {
-                const uint32_t fl = (X.f[sg] >> 8) & 0xffu;
-                // the high-x face of column 2l+1 is the low-x face of the next lane's column 2l+2
-                T u1 = __shfl_down(X.u[sg][0], 1, 64);
+            for (int q = 0; q < NQ; ++q) {
+                const int sg = q / CP, j = q % CP;
+                const uint32_t fl = (X.f[sg] >> (16 * j + 8)) & 0xffu;
+                // the high-x face of the pair's second column is the low-x face of the next pair: the lane's
+                // own next pair, or the first pair of the segment in the next lane
+                T u1;
                 bool have_hi = true;
-                if (sg + 1 < NSEG) {
-                    const T wrap = __shfl(X.u[sg + 1][0], 0, 64);
-                    if (lane == 63) u1 = wrap;
+                if (j + 1 < CP) {
+                    u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
                 } else {
-                    have_hi = lane < 63;
+                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);
+                    if (sg + 1 < NSEG) {
+                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], 0, 64);
+                        if (lane == 63) u1 = wrap;
+                    } else {
+                        have_hi = lane < 63;
+                    }
                 }
                 const bool ok = row_ok && have_hi && relaxes(fl);
-                const int a = sg * 128 + 64 + lane;
-                const T u0 = X.u[sg][1];
+                const int a = vpos(q, 1);
+                const T u0 = X.u[q][1];
                 const T v0 = v0row[a], v1 = v1row[a];
-                const T w0 = X.w[sg][1], w1 = Y.w[sg][1];
+                const T w0 = X.w[q][1], w1 = Y.w[q][1];
                 const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
                 T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
                 if (omega != (T)1) dd = omega * dd;
                 const bool self = fl & FL_SELF_FLUID;
-                if (ok && (fl & FL_XM) && self) X.u[sg][1] = u0 + dd;
-                send[sg] = (ok && (fl & FL_XP)) ? dd : (T)0;
+                if (ok && (fl & FL_XM) && self) X.u[q][1] = u0 + dd;
+                send[q] = (ok && (fl & FL_XP)) ? dd : (T)0;
                 if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
                 if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
-                if (ok && (fl & FL_ZM) && self) X.w[sg][1] = w0 + dd;
-                if (ok && (fl & FL_ZP)) Y.w[sg][1] = w1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[q][1] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[q][1] = w1 - dd;
             }
 #pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) {   // deliver -dd to the right-hand neighbour's low-x face
-                T got = __shfl_up(send[sg], 1, 64);
-                bool any = lane > 0;
-                if (sg > 0) {
-                    const T wrap = __shfl(send[sg - 1], 63, 64);
-                    if (lane == 0) { got = wrap; any = true; }
+            for (int q = 0; q < NQ; ++q) {   // deliver -dd to the low-x face of the pair on the right
+                const int sg = q / CP, j = q % CP;
+                T got;
+                bool any = true;
+                if (j > 0) {
+                    got = send[q > 0 ? q - 1 : 0];
+                } else {
+                    got = __shfl_up(send[sg * CP + CP - 1], 1, 64);
+                    any = lane > 0;
+                    if (sg > 0) {
+                        const T wrap = __shfl(send[(sg > 0 ? sg : 1) * CP - 1], 63, 64);
+                        if (lane == 0) { got = wrap; any = true; }
+                    }
                 }
-                if (any && got != (T)0) X.u[sg][0] = X.u[sg][0] - got;
+                if (any && got != (T)0) X.u[q][0] = X.u[q][0] - got;
             }
         }
     };
-    auto store_plane = [&](RowPlane<T, NSEG>& X, int p) {
+    auto store_plane = [&](RowPlane<T, NQ, NSEG>& X, int p) {
         const T* row = vrow(p, ry);
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
-            if (col_core[sg]) {
-                const int64_t i = (int64_t)p * g.sz + rowoff + sg * 128;
-                *reinterpret_cast<Pair<T>*>(uo + i) = Pair<T>{X.u[sg][0], X.u[sg][1]};
-                *reinterpret_cast<Pair<T>*>(vo + i) = Pair<T>{row[sg * 128 + lane], row[sg * 128 + 64 + lane]};
-                *reinterpret_cast<Pair<T>*>(wo + i) = Pair<T>{X.w[sg][0], X.w[sg][1]};
+            const int64_t i = (int64_t)p * g.sz + rowoff + sg * C::SEGW;
+            bool all = true, none = true;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { all = all && pair_core[sg * CP + j]; none = none && !pair_core[sg * CP + j]; }
+            if (none) continue;
+            VecT pu, pv, pw;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) {
+                const int q = sg * CP + j;
+                pu.e[2 * j] = X.u[q][0]; pu.e[2 * j + 1] = X.u[q][1];
+                pv.e[2 * j] = row[vpos(q, 0)]; pv.e[2 * j + 1] = row[vpos(q, 1)];
+                pw.e[2 * j] = X.w[q][0]; pw.e[2 * j + 1] = X.w[q][1];
+            }
+            if (all) {
+                *reinterpret_cast<VecT*>(uo + i) = pu;
+                *reinterpret_cast<VecT*>(vo + i) = pv;
+                *reinterpret_cast<VecT*>(wo + i) = pw;
+            } else {   // the lane straddles the edge of the stored core: pair by pair
+#pragma unroll
+                for (int j = 0; j < CP; ++j)
+                    if (pair_core[sg * CP + j]) {
+                        using Pr = Vec<T, 2>;
+                        *reinterpret_cast<Pr*>(uo + i + 2 * j) = Pr{{pu.e[2 * j], pu.e[2 * j + 1]}};
+                        *reinterpret_cast<Pr*>(vo + i + 2 * j) = Pr{{pv.e[2 * j], pv.e[2 * j + 1]}};
+                        *reinterpret_cast<Pr*>(wo + i + 2 * j) = Pr{{pw.e[2 * j], pw.e[2 * j + 1]}};
+                    }
             }
         }
     };

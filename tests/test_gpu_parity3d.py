@@ -14,7 +14,7 @@ from tests.util3d import assert_fields_equal, make_pair, rel_l2
 pytestmark = pytest.mark.gpu
 
 # cubic, non-cubic, ragged (not multiples of the 64x4 block), minimal
-SHAPES = [(16, 16, 16), (24, 48, 24), (70, 5, 6), (33, 9, 17), (3, 3, 3), (4, 3, 5), (130, 7, 4)]
+SHAPES = [(16, 16, 16), (24, 48, 24), (70, 5, 6), (33, 9, 17), (3, 3, 3), (4, 3, 5), (130, 7, 4), (260, 5, 6), (520, 5, 6), (1030, 4, 5)]
 
 
 def test_scene_sphere_influence(fsamd):

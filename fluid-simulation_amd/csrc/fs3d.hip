@@ -18,6 +18,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "fs_comm.hpp"
@@ -85,6 +88,18 @@ struct fs3d_sim {
     double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
     std::string err;
 };
+
+// Raises a kernel's dynamic LDS limit once per kernel and device (the call is not free, and a sweep
+// launches the same kernel thousands of times).
+inline hipError_t allow_lds(fs3d_sim* s, const void* kern, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kern, s->device})) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.insert({kern, s->device});
+    return e;
+}
 
 namespace {
 
@@ -409,7 +424,7 @@ int launch_fused_sweep(fs3d_sim* s) {
     constexpr int TX = 64, TY = 8;
     using C = FusedTile<T, TX, TY>;
     auto kern = k_rb_fused<T, TX, TY>;
-    SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
+    SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
     const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
@@ -432,7 +447,7 @@ template <typename T, int NSEG, int CP>
 int launch_rows_sweep(fs3d_sim* s) {
     using C = RowsCfg<T, NSEG, CP>;
     auto kern = k_rb_rows<T, NSEG, CP>;
-    SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes()));
+    SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
     const int rows = std::min(C::RY, s->ny);
@@ -641,7 +656,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         return FS_OK;
     }
     auto go = [&](auto kern, size_t lds) -> int {
-        SIM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SIM_HIP(allow_lds(s, (const void*)kern, lds));
         const int tiles = div_up(s->nx, 64) * div_up(s->ny, 8);
         // workgroups a CU holds at once: limited by LDS (160 KiB) and, at 72 registers, to 3 x 8 waves
         const int per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / lds)));

@@ -24,6 +24,7 @@
 // exact.  Output goes to the other generation of the arrays, so workgroups
 // only read old data and need no ordering among themselves.
 #pragma once
+#include <type_traits>
 #include "fs_kernels3d.hpp"
 #include "fs_sweep_fused.hpp"
 
@@ -54,7 +55,7 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     using C = RowsCfg<T, NSEG, CP>;
     constexpr int NQ = C::NQ;
     using VecT = Vec<T, 2 * CP>;
-    using VecF = Vec<uint8_t, 2 * CP>;
+    using FlagWord = typename std::conditional<CP == 1, uint16_t, uint32_t>::type;   // the 2*CP flag bytes of a lane
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // [NPV][rows][W]; a row holds, per pair index q, the even columns of all lanes, then the odd ones:
     // the active cells of a row all have the same x parity, so a wave reads consecutive words
@@ -104,17 +105,15 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
             const bool in = pin && seg_in[sg];
             const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
             VecT pu, pv;
-            VecF pf;
+            uint32_t fw = CP == 1 ? 0x8080u : 0x80808080u;   // FL_SELF_OBJECT in every byte
+            static_assert(FL_SELF_OBJECT == 0x80u, "filler for columns outside the grid");
 #pragma unroll
-            for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; pf.e[k] = (uint8_t)FL_SELF_OBJECT; }
+            for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; }
             if (in) {
                 pu = *reinterpret_cast<const VecT*>(ui + i);
                 pv = *reinterpret_cast<const VecT*>(vi + i);
-                pf = *reinterpret_cast<const VecF*>(flags + i);
+                fw = *reinterpret_cast<const FlagWord*>(flags + i);
             }
-            uint32_t fw = 0;
-#pragma unroll
-            for (int k = 0; k < 2 * CP; ++k) fw |= (uint32_t)pf.e[k] << (8 * k);
             X.f[sg] = fw;
 #pragma unroll
             for (int j = 0; j < CP; ++j) { X.u[sg * CP + j][0] = pu.e[2 * j]; X.u[sg * CP + j][1] = pu.e[2 * j + 1]; }

@@ -66,7 +66,8 @@ struct fs3d_sim {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;        // halo traffic of the one-pass sweep, overlapped with its interior
-    hipEvent_t ev_bnd = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_comm = nullptr, ev_b = nullptr;
+    bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
     size_t esz = 4;
@@ -74,7 +75,7 @@ struct fs3d_sim {
     std::vector<Part> parts;
     int curv = 0, curd = 0;      // generation holding the current velocity (u,v,w) / density
     bool cells_dirty = true;
-    int halo_dirty = 3;          // halo planes that lag their owners: bit 0 velocity, bit 1 density
+    int halo_dirty = 7;          // halo planes that lag their owners: bit 0 velocity, bit 1 density, bit 2 scratch velocity
     double* dres = nullptr;      // 2 doubles per local part + 2 combined
     double* hres = nullptr;      // pinned mirror of the combined pair
     int* doob = nullptr;         // device flag: a backtrace left the slab's halo
@@ -261,18 +262,47 @@ void* base_flags(fs3d_sim*, Part& p, int) { return p.flags; }
 void* base_tmp(fs3d_sim*, Part& p, int k) { return p.tmp[k]; }
 void* base_cells(fs3d_sim*, Part& p, int) { return p.cells; }
 
-enum { HALO_VEL = 1, HALO_DEN = 2, HALO_ALL = 3 };
+enum { HALO_VEL = 1, HALO_DEN = 2, HALO_ALL = 3, HALO_TMP = 4 };
 
-// Brings the halo planes named in `need` up to date if they lag; `with_tmp` adds the scratch velocity.
-int refresh_halos(fs3d_sim* s, int need, bool with_tmp = false) {
+// Halo traffic runs on comm_stream and the main stream does not wait for it when it is queued: the next
+// kernel may be the interior of a one-pass sweep, which reads no halo plane.  Everything else that reads
+// halo planes, touches the communicator or hands data to the host calls join_halos first.
+int join_halos(fs3d_sim* s) {
+    if (!s->halo_pending) return FS_OK;
+    SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    s->halo_pending = false;
+    return FS_OK;
+}
+
+// Blocks the host until the handle's two streams are idle.
+int quiesce(fs3d_sim* s) {
+    FS_TRY(join_halos(s));
+    SIM_HIP(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+// Queues an exchange behind everything the main stream holds so far.
+int exchange_async(fs3d_sim* s, const std::vector<HaloOp>& ops) {
+    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));
+    SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
+    FS_TRY(exchange_halos(s, ops, s->comm_stream));
+    SIM_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
+    s->halo_pending = true;
+    return FS_OK;
+}
+
+// Brings the halo planes named in `need` (HALO_* bits) up to date if they lag.  With `async` the main
+// stream is not made to wait for the exchange (see join_halos).
+int refresh_halos(fs3d_sim* s, int need, bool async = false) {
     if (s->nparts_global == 1) { s->halo_dirty = 0; return FS_OK; }
     const int todo = s->halo_dirty & need;
     std::vector<HaloOp> ops;
     if (todo & HALO_VEL) for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
     if (todo & HALO_DEN) ops.push_back({base_field_cur, 3, s->esz});
-    if (with_tmp) for (int k = 0; k < 3; ++k) ops.push_back({base_tmp, k, s->esz});
-    if (!ops.empty()) FS_TRY(exchange_halos(s, ops));
+    if (todo & HALO_TMP) for (int k = 0; k < 3; ++k) ops.push_back({base_tmp, k, s->esz});
+    if (!ops.empty()) FS_TRY(exchange_async(s, ops));
     s->halo_dirty &= ~todo;
+    if (!async) FS_TRY(join_halos(s));
     return FS_OK;
 }
 
@@ -285,6 +315,7 @@ void halos_after_sweeps(fs3d_sim* s) {
 
 int refresh_flags(fs3d_sim* s) {
     if (!s->cells_dirty) return FS_OK;
+    FS_TRY(join_halos(s));
     FS_TRY(exchange_halos(s, {{base_cells, 0, 1}}));
     for (Part& p : s->parts) {
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
@@ -298,9 +329,9 @@ int refresh_flags(fs3d_sim* s) {
 }
 
 // Everything a compute entry point needs before its first kernel.
-int prepare(fs3d_sim* s, int need = HALO_VEL, bool with_tmp = false) {
+int prepare(fs3d_sim* s, int need = HALO_VEL, bool async = false) {
     FS_TRY(refresh_flags(s));
-    return refresh_halos(s, need, with_tmp);
+    return refresh_halos(s, need, async);
 }
 
 // ---- projection -----------------------------------------------------------
@@ -375,8 +406,14 @@ int one_pass_driver(fs3d_sim* s, Launch launch) {
         s->curv ^= 1;
         return FS_OK;
     }
-    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));               // everything queued so far
+    // Sweep k on two streams.  comm_stream: B_k (the two owned planes next to each interface), then X_k
+    // (their exchange).  Main stream: I_k (the interior).  I_k reads and overwrites owned planes only, so it
+    // waits for B_{k-1} (which read the generation I_k overwrites and produced planes I_k reads) but not
+    // for X_{k-1}; B_k reads halo planes and follows X_{k-1} in stream order.  Whoever needs the halos of
+    // the last sweep calls join_halos.
+    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));               // I_{k-1} and everything queued before it
     SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
+    if (s->halo_pending) SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_b, 0));   // B_{k-1}, or the exchange queued before sweep 1
     for (Part& p : s->parts) {
         const int own_lo = p.H, own_hi = p.H + p.own_planes();
         const int lo_end = p.has_lo ? std::min(own_lo + 2, own_hi) : own_lo;
@@ -386,12 +423,13 @@ int one_pass_driver(fs3d_sim* s, Launch launch) {
         if (hi_beg > lo_end) launch(p, lo_end, hi_beg, s->stream);
     }
     SIM_HIP(hipGetLastError());
+    SIM_HIP(hipEventRecord(s->ev_b, s->comm_stream));
     s->curv ^= 1;   // the halo operators below address the new generation
     std::vector<HaloOp> ops;
     for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
     FS_TRY(exchange_halos(s, ops, s->comm_stream));
     SIM_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
-    SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    s->halo_pending = true;
     return FS_OK;
 }
 
@@ -519,6 +557,7 @@ int oob_status(fs3d_sim* s) {
 }
 
 int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
+    FS_TRY(join_halos(s));   // one stream at a time on the communicator
     double* comb = s->dres + 2 * s->nlocal;
     hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
     SIM_HIP(hipGetLastError());
@@ -528,7 +567,7 @@ int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
             FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
     }
     SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     if (sum) *sum = s->hres[0];
     if (mx) *mx = s->hres[1];
     return oob_status(s);
@@ -551,7 +590,7 @@ int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
                            F<T>(p, s->curv, 2), s->dres);
         SIM_HIP(hipGetLastError());
         SIM_HIP(hipMemcpyAsync(s->hres, s->dres, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        SIM_HIP(hipStreamSynchronize(s->stream));
+        FS_TRY(quiesce(s));
         *change = s->hres[0];
         return FS_OK;
     }
@@ -568,6 +607,7 @@ int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
 
 template <typename T>
 int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
+    FS_TRY(join_halos(s));   // the top owned plane reads w of the first halo plane
     for (int k = 0; k < s->nlocal; ++k) {
         Part& p = s->parts[k];
         hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv, 0),
@@ -600,7 +640,9 @@ int sweep_with_change(fs3d_sim* s, double* change) {
 // nearly the same number of sweeps, so this costs one or two evaluations and stops at the exact sweep).
 template <typename T>
 int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
-    FS_TRY(prepare(s));
+    // the interior of a one-pass sweep reads no halo plane: let the exchange run beside it
+    const bool one_pass = s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
+    FS_TRY(prepare(s, HALO_VEL, one_pass));
     const fs3d_config& c = s->cfg;
     const bool adaptive = c.check_every == 0;
     const int every = std::max(1, c.check_every);
@@ -676,7 +718,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
 // field the reflection needs later).
 template <typename T>
 int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false, bool reflect = false) {
-    FS_TRY(prepare(s, HALO_ALL, q_from_tmp));
+    FS_TRY(prepare(s, HALO_ALL | (q_from_tmp ? HALO_TMP : 0)));
     const bool slab = s->nparts_global > 1;
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
     for (Part& p : s->parts) {
@@ -692,7 +734,9 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
     SIM_HIP(hipGetLastError());
     s->curv = ov;
     s->curd = od;
-    s->halo_dirty = HALO_ALL;
+    s->halo_dirty |= HALO_ALL | (copy_to_tmp ? HALO_TMP : 0);
+    // start the exchange of the new planes now; whoever needs them waits (join_halos)
+    FS_TRY(refresh_halos(s, HALO_ALL | HALO_TMP, true));
     return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }
 
@@ -719,7 +763,8 @@ int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
     for (Part& p : s->parts)
         for (int k = 0; k < 4; ++k)
             if (!p.mc[k]) SIM_HIP(hipMalloc(&p.mc[k], p.n * s->esz));
-    FS_TRY(prepare(s, HALO_ALL));   // the backward trace reads the halo planes of the forward result
+    // the backward trace reads the halo planes of the forward result
+    FS_TRY(prepare(s, HALO_ALL | (q_from_tmp ? HALO_TMP : 0)));
     const int cv = s->curv, pv = s->curv ^ 1, cd = s->curd, pd = s->curd ^ 1;
     for (Part& p : s->parts) {
         const int zb = p.H, ze = p.H + p.own_planes();
@@ -737,8 +782,8 @@ int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
         std::swap(p.f[cd][3], p.mc[3]);
     }
     SIM_HIP(hipGetLastError());
-    s->halo_dirty = HALO_ALL;
-    return FS_OK;
+    s->halo_dirty |= HALO_ALL | (copy_to_tmp ? HALO_TMP : 0);
+    return refresh_halos(s, HALO_ALL | HALO_TMP, true);
 }
 
 template <typename T>
@@ -769,6 +814,7 @@ int step(fs3d_sim* s, double dt) {
             // the staged kernel forms ur while it loads ut and uh: no reflection pass
             FS_TRY(advect<T>(s, 0.5 * dt, true, 0, false, true));
         } else {
+            FS_TRY(prepare(s, HALO_VEL | HALO_TMP));   // the reflection runs over halo planes too
             for (Part& p : s->parts)
                 hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
                                    F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), (const T*)p.tmp[0], (const T*)p.tmp[1],
@@ -841,7 +887,7 @@ int downsample(fs3d_sim* s, int f, void* host, size_t count) {
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host, dev, total * sizeof(T), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);   // (halo traffic in flight touches halo planes only)
     (void)hipFree(dev);
     SIM_HIP(e);
     return FS_OK;
@@ -903,7 +949,7 @@ int scatter_to(fs3d_sim* s, Part& p, const Stamp& st, int field, float scale, in
     if (cell_type >= 0)
         hipLaunchKernelGGL(k_scatter_cells, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, (uint8_t)cell_type, p.cells);
     SIM_HIP(hipGetLastError());
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     (void)hipFree(didx); (void)hipFree(dval);
     return FS_OK;
 }
@@ -1023,6 +1069,7 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     SIM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_bnd, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+    SIM_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
     SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 3)));
     SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 3, hipHostMallocDefault));
     // the out-of-halo flag sits behind the combined pair, so that the copy of a reduction result brings it along
@@ -1043,7 +1090,7 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     FS_TRY(init_cells(s));
     for (int k = 0; k < 3; ++k) SIM_HIP(hipEventRecord(s->ev[k], s->stream));
     SIM_HIP(hipEventRecord(s->ev[3], s->stream));
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     return FS_OK;
 }
 
@@ -1153,6 +1200,7 @@ int fs3d_slab_range(const fs3d_sim* s, int* z0, int* z1, int* halo) {
 void fs3d_destroy(fs3d_sim* s) {
     if (!s) return;
     DeviceGuard guard(s->device);
+    if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
     free_parts(s);
@@ -1162,6 +1210,7 @@ void fs3d_destroy(fs3d_sim* s) {
     if (s->comm_stream) { (void)hipStreamSynchronize(s->comm_stream); (void)hipStreamDestroy(s->comm_stream); }
     if (s->ev_bnd) (void)hipEventDestroy(s->ev_bnd);
     if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
+    if (s->ev_b) (void)hipEventDestroy(s->ev_b);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1177,7 +1226,7 @@ int fs3d_reset(fs3d_sim* s) {
     *s->hoob = 0;
     s->stats = fs3d_stats{};
     s->halo_dirty = HALO_ALL;
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     return FS_OK;
 }
 
@@ -1211,7 +1260,7 @@ int fs3d_set_field(fs3d_sim* s, int which, const void* host, size_t count) {
     owned_range(s, &z0, &z1);
     const size_t plane = (size_t)s->nx * s->ny;
     if (count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     for (Part& p : s->parts) {
         char* dst = (char*)field_ptr(s, p, which) + (size_t)p.H * plane * s->esz;
         const char* src = (const char*)host + (size_t)(p.z0 - z0) * plane * s->esz;
@@ -1234,7 +1283,7 @@ int fs3d_get_field(fs3d_sim* s, int which, void* host, size_t count) {
         for (Part& p : s->parts) SIM_HIP(hipMemsetAsync(p.tmp[0], 0, p.n * s->esz, s->stream));
         FS_TRY(DISPATCH(s, residual, s, nullptr, nullptr, true));
     }
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     for (Part& p : s->parts) {
         const char* src = (const char*)field_ptr(s, p, which) + (size_t)p.H * plane * s->esz;
         char* dst = (char*)host + (size_t)(p.z0 - z0) * plane * s->esz;
@@ -1248,7 +1297,7 @@ int fs3d_get_field_plane(fs3d_sim* s, int which, int z, void* host, size_t count
     if (!host || which < FS_FIELD_U || which > FS_FIELD_DENSITY) return set_err(s, FS_EINVAL, "bad field or null pointer");
     const size_t plane = (size_t)s->nx * s->ny;
     if (count != plane) return set_err(s, FS_EINVAL, "count must be nx*ny");
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     for (Part& p : s->parts)
         if (z >= p.z0 && z < p.z1) {
             const char* src = (const char*)field_ptr(s, p, which) + (size_t)(z - p.g.gz0) * plane * s->esz;
@@ -1264,7 +1313,7 @@ int fs3d_set_cell_types(fs3d_sim* s, const uint8_t* host, size_t count) {
     owned_range(s, &z0, &z1);
     const size_t plane = (size_t)s->nx * s->ny;
     if (!host || count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     for (Part& p : s->parts) {
         std::vector<uint8_t> h((size_t)p.own_planes() * plane);
         for (int z = p.z0; z < p.z1; ++z)
@@ -1287,7 +1336,7 @@ int fs3d_get_cell_types(fs3d_sim* s, uint8_t* host, size_t count) {
     owned_range(s, &z0, &z1);
     const size_t plane = (size_t)s->nx * s->ny;
     if (!host || count != plane * (size_t)(z1 - z0)) return set_err(s, FS_EINVAL, "count does not match the owned planes");
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     for (Part& p : s->parts)
         SIM_HIP(hipMemcpy(host + (size_t)(p.z0 - z0) * plane, p.cells + (size_t)p.H * plane, (size_t)p.own_planes() * plane,
                           hipMemcpyDeviceToHost));
@@ -1376,6 +1425,7 @@ int fs3d_time_sweeps(fs3d_sim* s, int n, double* ms) {
     FS_TRY(prepare(s));
     SIM_HIP(hipEventRecord(s->ev[0], s->stream));
     for (int i = 0; i < n; ++i) FS_TRY(DISPATCH(s, sweep_once, s));
+    FS_TRY(join_halos(s));   // the time includes the halo traffic of the last sweep
     SIM_HIP(hipEventRecord(s->ev[1], s->stream));
     SIM_HIP(hipEventSynchronize(s->ev[1]));
     float t = 0;
@@ -1515,7 +1565,7 @@ int fs3d_load(fs3d_sim* s, const char* path) {
 int fs3d_get_stats(fs3d_sim* s, fs3d_stats* out) {
     SIM_GUARD(s);
     if (!out) return FS_EINVAL;
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     float a = 0, b = 0, c = 0;
     if (s->stats.step > 0) {
         (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
@@ -1531,7 +1581,7 @@ int fs3d_synchronize(fs3d_sim* s) {
     SIM_GUARD(s);
     if (s->nparts_global > 1)
         SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    SIM_HIP(hipStreamSynchronize(s->stream));
+    FS_TRY(quiesce(s));
     return oob_status(s);
 }
 

@@ -440,3 +440,25 @@ def test_stopping_metric_is_the_residual_of_the_field_left_behind(fsamd, shape, 
         o.rb_sweep()
     assert_fields_equal(o, g, "uvw", what="check sweeps")
     assert l2 == pytest.approx(o.residual_l2(), rel=1e-12)
+
+
+@pytest.mark.parametrize("slabs", [2, 5])
+def test_slabs_with_overlapped_halo_traffic_at_a_size_where_kernels_overlap(fsamd, slabs):
+    # halo exchanges run on a second stream beside the interior sweeps and are only waited for by their
+    # consumers; at this size the kernels are long enough to really overlap, so a missing dependency shows
+    n = 128
+    cfg = dict(step_mode=1, stop_mode=2, tol=2e-5, max_iters=60, check_every=0)
+    a = fsamd.FluidSim3D(n, n, n, **cfg)
+    b = fsamd.FluidSim3D(n, n, n, local_slabs=slabs, **cfg)
+    for g in (a, b):
+        g.sphere_influence(n / 10.0)
+        g.solid_sphere(9.0, 70.0, 40.0, 60.0)
+    for it in range(4):
+        for g in (a, b):
+            g.fill_sphere_influence(n / 10.0, it)
+            g.advance(1.0 / 30.0)
+        assert a.stats().sweeps_step == b.stats().sweeps_step
+        for k in range(4):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), (it, k)
+    da, db = a.diagnostics(), b.diagnostics()
+    assert da.max_speed == db.max_speed and da.kinetic_energy == pytest.approx(db.kinetic_energy, rel=1e-12)

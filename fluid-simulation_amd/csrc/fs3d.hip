@@ -450,7 +450,7 @@ inline int pick_chunks(int planes, int tiles, int slots) {
     for (int c = 1; c <= std::max(1, planes / 8); ++c) {
         const int zc = div_up(planes, c);
         const int rounds = div_up(tiles * div_up(planes, zc), slots);
-        const double cost = (double)rounds * (zc + 7);
+        const double cost = (double)rounds * (zc + 6);
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
@@ -514,6 +514,7 @@ int launch_one_pass_sweep(fs3d_sim* s) {
             return launch_rows_sweep<T, 2, 1>(s);
         } else {
         if (s->nx % 4 == 0 && s->nx <= 256) return launch_rows_sweep<T, 1, 2>(s);
+        if (s->nx % 4 == 0) return launch_rows_sweep<T, 2, 2>(s);
         if (s->nx <= 128) return launch_rows_sweep<T, 1, 1>(s);
         if (s->nx <= 256) return launch_rows_sweep<T, 2, 1>(s);
         return launch_rows_sweep<T, 4, 1>(s);

@@ -7,18 +7,19 @@
 // (pair j, column c of the pair), so that one load or store of a lane moves
 // 2*CP elements (16 bytes: CP = 2 for 4-byte elements when nx is a multiple
 // of 4, CP = 1 for 8-byte elements).  The wave marches along z.  For its
-// columns a lane keeps u and w of the five planes in flight in registers: the
+// columns a lane keeps u and w of the four planes in flight in registers: the
 // two cells a w face touches lie in the same column, so w never leaves the
 // lane, and the u faces a cell shares with its x neighbours live in the next
 // pair of the lane or in the neighbouring lane and move by wave shuffles.
-// Only v, which couples rows and therefore waves, is staged in LDS (three
+// Only v, which couples rows and therefore waves, is staged in LDS (two
 // planes).  Every face is read once and written once per sweep (25 B per cell
 // instead of the 50 B of two half-sweep launches).
 //
-// Per step t the workgroup applies colour 0 to plane t and colour 1 to plane
-// t-2; a cell visit (advection-reflection/main.cpp:198-233) touches only the
-// cell's own six faces and black on plane p needs red finished on p-1, p,
-// p+1, so the two-plane lag reproduces two separate half-sweeps exactly.
+// Per step t the workgroup applies colour 0 to plane t and then colour 1 to
+// plane t-1; a cell visit (advection-reflection/main.cpp:198-233) touches only
+// the cell's own six faces and black on plane p needs red finished on p-1, p,
+// p+1, which the one-plane lag provides (see the step below), so the result is
+// that of two separate half-sweeps exactly.
 // Tiles overlap their neighbours by two cells in x and y (and chunks by two
 // planes in z): the outer two rings of a tile go stale, the stored core is
 // exact.  Output goes to the other generation of the arrays, so workgroups
@@ -43,7 +44,7 @@ struct RowsCfg {
     static constexpr int SEGW = 128 * CP;   // columns of one segment
     static constexpr int W = SEGW * NSEG;
     static constexpr int NQ = NSEG * CP;
-    static constexpr int NPV = 3;           // v planes in LDS
+    static constexpr int NPV = 2;           // v planes in LDS: the planes of the two colours of a step
     static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
 };
 
@@ -95,7 +96,7 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
             pair_core[sg * CP + j] = row_core && x + 2 * j >= cx_lo && x + 2 * j < cx_hi;
     }
 
-    RowPlane<T, NQ, NSEG> P0, P1, P2, P3, P4;
+    RowPlane<T, NQ, NSEG> P0, P1, P2, P3;
     VecT vst[NSEG];
 
     auto load_uf = [&](RowPlane<T, NQ, NSEG>& X, int p) {   // u, flags and the v staging registers of plane p
@@ -262,34 +263,37 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
         }
     };
 
-    // Step t: A = plane t-2, B = t-1, Cc = t, D = t+1, E = t+2.  u/flags/v of a plane are fetched one
-    // step before its first colour, w two steps before (it is the high-z face of the plane below).
-#define FS_ROWS_STEP(A, B, Cc, D, E)                                            \
+    // Step t: M = plane t-1, Cc = t, N = t+1, F = t+2.  The first colour runs on plane t and then, in the
+    // same thread, the second colour on plane t-1.  A second-colour cell of plane t-1 needs the first colour
+    // finished on its six neighbours: those in plane t-1 and the one in plane t-2 ran in earlier steps
+    // (barriers since), and the one in plane t is the cell directly above it, in the same column, i.e. the
+    // same lane a moment earlier (w never leaves the lane).  u/flags/v of a plane are fetched one step before
+    // its first colour, w two steps before (it is the high-z face of the plane below).
+#define FS_ROWS_STEP(M, Cc, N, F)                                               \
     {                                                                           \
         if (t >= lb && t < le) stage_v(t);                                      \
-        load_uf(D, t + 1);                                                      \
-        load_w(E, t + 2);                                                       \
+        load_uf(N, t + 1);                                                      \
+        load_w(F, t + 2);                                                       \
         __syncthreads();                                                        \
-        if (t >= s0b && t < s0e) relax(Cc, D, t, 0);                            \
-        if (t - 2 >= s1b && t - 2 < s1e) relax(A, B, t - 2, 1);                 \
+        if (t >= s0b && t < s0e) relax(Cc, N, t, 0);                            \
+        if (t - 1 >= s1b && t - 1 < s1e) relax(M, Cc, t - 1, 1);                \
         __syncthreads();                                                        \
-        if (t - 2 >= c0 && t - 2 < c1) store_plane(A, t - 2);                   \
+        if (t - 1 >= c0 && t - 1 < c1) store_plane(M, t - 1);                   \
         ++t;                                                                    \
         if (t > tend) break;                                                    \
     }
 
     int t = lb - 1;
-    const int tend = c1 + 1;
-    load_w(P3, lb);   // at the first step (t = lb-1) plane lb is "D"
+    const int tend = c1;
+    load_w(P2, lb);   // at the first step (t = lb-1) plane lb is "N"
     // keep the compiler from treating never-loaded planes as undefined
-    load_w(P0, -1); load_w(P1, -1); load_w(P2, -1); load_w(P4, -1);
-    load_uf(P0, -1); load_uf(P1, -1); load_uf(P2, -1); load_uf(P3, -1); load_uf(P4, -1);
+    load_w(P0, -1); load_w(P1, -1); load_w(P3, -1);
+    load_uf(P0, -1); load_uf(P1, -1); load_uf(P2, -1); load_uf(P3, -1);
     for (;;) {
-        FS_ROWS_STEP(P0, P1, P2, P3, P4)
-        FS_ROWS_STEP(P1, P2, P3, P4, P0)
-        FS_ROWS_STEP(P2, P3, P4, P0, P1)
-        FS_ROWS_STEP(P3, P4, P0, P1, P2)
-        FS_ROWS_STEP(P4, P0, P1, P2, P3)
+        FS_ROWS_STEP(P0, P1, P2, P3)
+        FS_ROWS_STEP(P1, P2, P3, P0)
+        FS_ROWS_STEP(P2, P3, P0, P1)
+        FS_ROWS_STEP(P3, P0, P1, P2)
     }
 #undef FS_ROWS_STEP
 }

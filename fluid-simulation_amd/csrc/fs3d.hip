@@ -494,7 +494,9 @@ int launch_rows_sweep(fs3d_sim* s) {
     return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
         FusedRanges r = fused_ranges<T>(p);
         r.z0 = z0; r.z1 = z1;
-        const int nchunks = pick_chunks(z1 - z0, ntx * nty, s->num_cus);
+        // the narrow variants fit 64 registers: two workgroups of 16 waves share a CU
+        constexpr int per_cu = NSEG * CP * sizeof(T) <= 8 ? 2 : 1;
+        const int nchunks = pick_chunks(z1 - z0, ntx * nty, per_cu * s->num_cus);
         r.zchunk = div_up(z1 - z0, nchunks);
         dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
         hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),

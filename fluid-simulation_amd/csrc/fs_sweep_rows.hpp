@@ -49,7 +49,7 @@ struct RowsCfg {
 };
 
 template <typename T, int NSEG, int CP>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, (NSEG * CP * sizeof(T) <= 8 ? 8 : 4))
 k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
           FusedRanges r, int ntx, int nty, int rows) {

@@ -132,14 +132,13 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         return fast_finish(tr, t);
     };
 
-    auto compute = [&](int z) {
+    auto compute = [&](int z, uint32_t fl) {
         const int gz = z + g.gz0;
         const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
         const OFF i = e * (OFF)sizeof(T);
         T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
         const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
         if (interior) {
-            const uint32_t fl = flags[e];
             const T four = (T)4, two = (T)2;
             const bool fluid = fl & FL_SELF_FLUID;
             const T* Uc = plane(VF + 0, z) + wl; const T* Uzm = plane(VF + 0, z - 1) + wl;
@@ -181,8 +180,12 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     for (int p = c0 - R; p <= c0 + R; ++p) { fetch(p); commit(p); }
     __syncthreads();
     for (int z = c0; z < c1; ++z) {
+        // the flag byte is asked for before the plane that is fetched ahead: waiting for it then leaves
+        // those loads in flight (loads return in order)
+        uint32_t fl = FL_SELF_OBJECT;
+        if (mine) fl = flags[((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x];
         fetch(z + R + 1);
-        if (mine) compute(z);
+        if (mine) compute(z, fl);
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
         __syncthreads();
     }

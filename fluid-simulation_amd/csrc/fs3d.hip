@@ -586,6 +586,7 @@ int snapshot_velocity(fs3d_sim* s) {   // main.cpp:192-196; the other generation
 
 template <typename T>
 int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
+    FS_TRY(join_halos(s));   // the planes next to a slab interface were swept on the second stream
     if (s->cfg.ordering == FS_ORDER_LEXICOGRAPHIC) {
         Part& p = s->parts[0];
         hipLaunchKernelGGL(k_change_serial<T>, dim3(1), dim3(64), 0, s->stream, p.g, F<T>(p, s->curv ^ 1, 0),

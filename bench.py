@@ -67,7 +67,7 @@ def cpu_baseline(n, sweeps_per_step, sample_sweeps=None):
     o.sphere_influence(n / 10.0)
     cells = n ** 3
     if sample_sweeps is None:
-        sample_sweeps = max(2, min(40, int(2.0e9 / (cells * 60))))   # about 10-20 s of sweeps
+        sample_sweeps = max(2, min(60, int(5.0 / (cells * 7e-9))))   # about 5 s of sweeps at ~7 ns per cell
     t = time.perf_counter()
     o.project_rb(stop_mode=0, max_iter=sample_sweeps)
     t_sweep = (time.perf_counter() - t) / sample_sweeps

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=0, help="cubic grid size override")
+    ap.add_argument("--solver", choices=["sweeps", "multigrid"], default="sweeps",
+                    help="sweeps: red-black Gauss-Seidel only (the north star's solver); multigrid: V-cycles around them")
     ap.add_argument("--local-slabs", type=int, default=1,
                     help="cut each rank's planes into this many z-slabs on its own GPU (rehearses the slab path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +118,7 @@ def main():
     sim = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
                         dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
-                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode, local_slabs=a.local_slabs,
+                        check_every=a.check_every, omega=a.omega, step_mode=a.step_mode, local_slabs=a.local_slabs, solver=1 if a.solver == "multigrid" else 0,
                         buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
     scene_init, scene_step = scenes.SCENES[a.scene]
     scene_init(sim)
@@ -173,7 +175,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{a.scene.replace('_', ' ')} {nx}x{ny}x{nz}, dt 1/30, "
-                            f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}, "
+                            f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}"
+                            f"{' inside multigrid V(2,2) cycles' if a.solver == 'multigrid' else ''}, "
                             f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, "
                             + ("residual evaluated from one sweep before the previous step's count, then every sweep"
                                if a.check_every == 0 else f"checked every {a.check_every}"),

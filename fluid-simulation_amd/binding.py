@@ -31,6 +31,7 @@ STEP_REFERENCE, STEP_REFLECTION = 0, 1
 SWEEP_FUSED, SWEEP_TWO_PASS, SWEEP_FUSED_LDS = 0, 1, 2
 ADVECT_TILED, ADVECT_DIRECT = 0, 1
 ADVECTION_SEMI_LAGRANGE, ADVECTION_MACCORMACK = 0, 1
+SOLVER_SWEEPS, SOLVER_MULTIGRID = 0, 1
 COMM_ID_BYTES = 128
 
 # every symbol include/fluidsim_amd.h declares
@@ -41,7 +42,7 @@ EXPORTS = [
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
-    "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fsamd_comm_unique_id", "fsamd_comm_selftest",
+    "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fsamd_comm_unique_id", "fsamd_comm_selftest",
     "fs3d_create_slab", "fs3d_slab_range",
     "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
     "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
@@ -52,7 +53,7 @@ class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("dtype", C.c_int32), ("ordering", C.c_int32), ("stop_mode", C.c_int32),
         ("max_iters", C.c_int32), ("check_every", C.c_int32), ("step_mode", C.c_int32), ("local_slabs", C.c_int32),
-        ("sweep_kernel", C.c_int32), ("advect_kernel", C.c_int32), ("advection", C.c_int32), ("reserved", C.c_int32),
+        ("sweep_kernel", C.c_int32), ("advect_kernel", C.c_int32), ("advection", C.c_int32), ("solver", C.c_int32),
         ("tol", C.c_double), ("omega", C.c_double), ("buoyancy", C.c_double),
     ]
 
@@ -122,6 +123,7 @@ def load_library(path=None):
         "fs3d_synchronize": (I, [P]),
         "fs3d_diagnostics": (I, [P, C.POINTER(Diag)]),
         "fs3d_get_density_downsampled": (I, [P, I, P, C.c_size_t]),
+        "fs3d_mg_vcycle": (I, [P]),
         "fs3d_save": (I, [P, C.c_char_p]),
         "fs3d_load": (I, [P, C.c_char_p]),
         "fsamd_comm_unique_id": (I, [P]),
@@ -237,6 +239,9 @@ class FluidSim3D:
         if a.size != self.count:
             raise ValueError("field size mismatch")
         self._chk(self.lib.fs3d_set_field(self.h, which, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def mg_vcycle(self):
+        self._chk(self.lib.fs3d_mg_vcycle(self.h))
 
     def vorticity(self):
         """|curl u| with the stencil of computeVorticity (3_fluid/FluidSim.h:220-229)."""

@@ -34,6 +34,7 @@
 #include "fs_sweep_rows.hpp"
 #include "fs_advect_tiled.hpp"
 #include "fs_diag3d.hpp"
+#include "fs_mg3d.hpp"
 
 using namespace fsamd;
 
@@ -52,6 +53,9 @@ struct Part {
     void* f[2][4] = {{nullptr}};
     void* tmp[3] = {nullptr};
     void* mc[4] = {nullptr};   // outputs of the MacCormack pass, allocated when the scheme is first used
+    struct MgRaw { int nx, ny, nz; void* a[6]; };   // wx, wy, wz, diag, e, r of one coarse level
+    std::vector<MgRaw> mg;     // multigrid levels, allocated when the solver is first used
+    bool mg_weights_ok = false;
     uint8_t* cells = nullptr;
     uint8_t* flags = nullptr;
     void* recv_lo = nullptr;   // staging for the interface w plane from the lower / upper rank
@@ -131,6 +135,7 @@ void free_parts(fs3d_sim* s) {
             for (int k = 0; k < 4; ++k) (void)hipFree(p.f[g][k]);
         for (int k = 0; k < 3; ++k) (void)hipFree(p.tmp[k]);
         for (int k = 0; k < 4; ++k) (void)hipFree(p.mc[k]);
+        for (auto& l : p.mg) for (void* a : l.a) (void)hipFree(a);
         (void)hipFree(p.cells); (void)hipFree(p.flags);
         (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
         (void)hipFree(p.partials);
@@ -325,6 +330,7 @@ int refresh_flags(fs3d_sim* s) {
     // the flags of a halo plane depend on cells beyond the halo: take them from the plane's owner
     FS_TRY(exchange_halos(s, {{base_flags, 0, 1}}));
     s->cells_dirty = false;
+    for (Part& p : s->parts) p.mg_weights_ok = false;
     return FS_OK;
 }
 
@@ -628,6 +634,91 @@ int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
     return FS_OK;
 }
 
+// ---- multigrid V-cycle (fs_mg3d.hpp) ---------------------------------------------------------------
+constexpr int kMgNu1 = 2, kMgNu2 = 2, kMgBottom = 30;
+constexpr double kMgAlpha = 2.0;
+
+template <typename T>
+MgLevel<T> mg_level(const Part::MgRaw& r) {
+    MgLevel<T> L;
+    L.d = MgDims{r.nx, r.ny, r.nz};
+    L.wx = (T*)r.a[0]; L.wy = (T*)r.a[1]; L.wz = (T*)r.a[2]; L.diag = (T*)r.a[3]; L.e = (T*)r.a[4]; L.r = (T*)r.a[5];
+    return L;
+}
+
+template <typename T>
+int mg_prepare(fs3d_sim* s, Part& p) {
+    auto grid_of = [](const Part::MgRaw& r, dim3* b, dim3* g) { *b = dim3(64, 4, 1); *g = dim3(div_up(r.nx, 64), div_up(r.ny, 4), r.nz); };
+    if (p.mg.empty()) {
+        int nx = s->nx, ny = s->ny, nz = p.g.nzl;
+        while (p.mg.size() < 16) {
+            nx = (nx + 1) / 2; ny = (ny + 1) / 2; nz = (nz + 1) / 2;
+            Part::MgRaw r{nx, ny, nz, {nullptr}};
+            for (void*& a : r.a) {
+                SIM_HIP(hipMalloc(&a, (size_t)nx * ny * nz * sizeof(T)));
+                SIM_HIP(hipMemsetAsync(a, 0, (size_t)nx * ny * nz * sizeof(T), s->stream));
+            }
+            p.mg.push_back(r);
+            if (nx <= 4 || ny <= 4 || nz <= 4) break;
+        }
+        p.mg_weights_ok = false;
+    }
+    if (p.mg_weights_ok) return FS_OK;
+    for (size_t l = 0; l < p.mg.size(); ++l) {
+        dim3 b, g;
+        grid_of(p.mg[l], &b, &g);
+        if (l == 0) hipLaunchKernelGGL(k_mg_weights_cells<T>, g, b, 0, s->stream, p.g, p.cells, mg_level<T>(p.mg[0]));
+        else hipLaunchKernelGGL(k_mg_weights_level<T>, g, b, 0, s->stream, mg_level<T>(p.mg[l - 1]), mg_level<T>(p.mg[l]));
+        hipLaunchKernelGGL(k_mg_diag<T>, g, b, 0, s->stream, mg_level<T>(p.mg[l]));
+    }
+    SIM_HIP(hipGetLastError());
+    p.mg_weights_ok = true;
+    return FS_OK;
+}
+
+template <typename T>
+int mg_smooth(fs3d_sim* s, const Part::MgRaw& r, int sweeps) {
+    dim3 b(64, 4, 1), g(div_up(div_up(r.nx, 2), 64), div_up(r.ny, 4), r.nz);
+    for (int it = 0; it < sweeps; ++it)
+        for (int colour = 0; colour < 2; ++colour)
+            hipLaunchKernelGGL(k_mg_smooth<T>, g, b, 0, s->stream, mg_level<T>(r), colour);
+    return FS_OK;
+}
+
+template <typename T>
+int mg_coarse_cycle(fs3d_sim* s, Part& p, size_t l) {
+    const Part::MgRaw& r = p.mg[l];
+    dim3 b(64, 4, 1), g(div_up(r.nx, 64), div_up(r.ny, 4), r.nz);
+    SIM_HIP(hipMemsetAsync(r.a[4], 0, (size_t)r.nx * r.ny * r.nz * sizeof(T), s->stream));
+    if (l + 1 == p.mg.size()) return mg_smooth<T>(s, r, kMgBottom);
+    FS_TRY(mg_smooth<T>(s, r, kMgNu1));
+    const Part::MgRaw& c = p.mg[l + 1];
+    dim3 gc(div_up(c.nx, 64), div_up(c.ny, 4), c.nz);
+    hipLaunchKernelGGL(k_mg_restrict<T>, gc, b, 0, s->stream, mg_level<T>(r), mg_level<T>(c));
+    FS_TRY(mg_coarse_cycle<T>(s, p, l + 1));
+    hipLaunchKernelGGL(k_mg_prolong<T>, g, b, 0, s->stream, mg_level<T>(r), mg_level<T>(c), (T)kMgAlpha);
+    return mg_smooth<T>(s, r, kMgNu2);
+}
+
+// One V-cycle on the current velocity (single slab, red-black order).
+template <typename T>
+int mg_vcycle(fs3d_sim* s) {
+    Part& p = s->parts[0];
+    FS_TRY(mg_prepare<T>(s, p));
+    for (int k = 0; k < kMgNu1; ++k) FS_TRY(sweep_once<T>(s));
+    const Part::MgRaw& c = p.mg[0];
+    dim3 b(64, 4, 1), gc(div_up(c.nx, 64), div_up(c.ny, 4), c.nz);
+    hipLaunchKernelGGL(k_mg_fine_residual<T>, gc, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
+                       F<T>(p, s->curv, 2), p.flags, mg_level<T>(c));
+    FS_TRY(mg_coarse_cycle<T>(s, p, 0));
+    dim3 gf(div_up(s->nx - 2, 64), div_up(s->ny - 2, 4), p.g.nzl - 2);
+    hipLaunchKernelGGL(k_mg_apply<T>, gf, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1), F<T>(p, s->curv, 2),
+                       p.flags, mg_level<T>(c), (T)kMgAlpha);
+    SIM_HIP(hipGetLastError());
+    for (int k = 0; k < kMgNu2; ++k) FS_TRY(sweep_once<T>(s));
+    return FS_OK;
+}
+
 // One sweep with the reference's change metric (main.cpp:189-254).
 template <typename T>
 int sweep_with_change(fs3d_sim* s, double* change) {
@@ -654,6 +745,19 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
     const int coarse = std::max(8, first / 4);   // sparse early checks, so that a stale hint cannot cost much
     int it = 0;
     double metric = 0;
+    if (c.solver == FS_SOLVER_MULTIGRID) {
+        // V-cycles; the stopping rule is evaluated after every cycle, a cycle counts as its fine sweeps
+        for (;;) {
+            FS_TRY(mg_vcycle<T>(s));
+            it += kMgNu1 + kMgNu2;
+            if (c.stop_mode == FS_STOP_L2_RESIDUAL) {
+                FS_TRY(residual<T>(s, &metric, nullptr, false));
+                metric /= s->resid_dt;
+                if (!(metric > c.tol)) break;
+            }
+            if (it >= c.max_iters) break;
+        }
+    } else
     for (;;) {
         const bool check = (adaptive ? (it + 1 >= first || (it + 1) % coarse == 0) : ((it + 1) % every == 0)) ||
                            (it + 1 >= c.max_iters);
@@ -1041,6 +1145,15 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (c->advect_kernel < FS_ADVECT_TILED || c->advect_kernel > FS_ADVECT_DIRECT) { *why = "bad advect_kernel"; return false; }
+    if (c->solver < FS_SOLVER_SWEEPS || c->solver > FS_SOLVER_MULTIGRID) { *why = "bad solver"; return false; }
+    if (c->solver == FS_SOLVER_MULTIGRID && (c->ordering != FS_ORDER_RED_BLACK || c->local_slabs > 1)) {
+        *why = "the multigrid solver needs red-black ordering and a single slab";
+        return false;
+    }
+    if (c->solver == FS_SOLVER_MULTIGRID && c->stop_mode == FS_STOP_L1_CHANGE) {
+        *why = "the multigrid solver stops on the residual or after a fixed count, not on the change of one sweep";
+        return false;
+    }
     if (c->advection < FS_ADVECTION_SEMI_LAGRANGE || c->advection > FS_ADVECTION_MACCORMACK) { *why = "bad advection"; return false; }
     if (!(c->omega > 0.0 && c->omega < 2.0)) { *why = "omega must lie in (0, 2)"; return false; }
     return true;
@@ -1119,7 +1232,7 @@ void fs3d_default_config(fs3d_config* c) {
     c->sweep_kernel = FS_SWEEP_FUSED;
     c->advect_kernel = FS_ADVECT_TILED;
     c->advection = FS_ADVECTION_SEMI_LAGRANGE;
-    c->reserved = 0;
+    c->solver = FS_SOLVER_SWEEPS;
     c->tol = 5.0;
     c->omega = 1.0;
     c->buoyancy = 0.0;
@@ -1467,6 +1580,14 @@ int fs3d_update(fs3d_sim* s, double t_step) {
 int fs3d_advance(fs3d_sim* s, double dt) {
     SIM_GUARD(s);
     return DISPATCH(s, step, s, dt);
+}
+
+int fs3d_mg_vcycle(fs3d_sim* s) {
+    SIM_GUARD(s);
+    if (s->nparts_global != 1 || s->cfg.ordering != FS_ORDER_RED_BLACK)
+        return set_err(s, FS_ESTATE, "the multigrid cycle needs red-black ordering and a single slab");
+    FS_TRY(prepare(s));
+    return DISPATCH(s, mg_vcycle, s);
 }
 
 int fs3d_diagnostics(fs3d_sim* s, fs3d_diag* out) {

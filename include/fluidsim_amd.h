@@ -91,6 +91,16 @@ enum {
                                        plain face average of the carrying velocity                  */
 };
 
+/* how a projection reduces the divergence between two evaluations of the stopping rule */
+enum {
+    FS_SOLVER_SWEEPS = 0,    /* Gauss-Seidel sweeps only: the reference (main.cpp:105-111)          */
+    FS_SOLVER_MULTIGRID = 1  /* V-cycles: 2 red-black sweeps, a coarse-grid correction of the same
+                                gradient form (levels of 2x2x2 blocks, red-black Gauss-Seidel on
+                                each, piecewise-constant transfer), 2 sweeps; the stopping rule is
+                                evaluated after every cycle and a cycle counts as 4 sweeps.  Same
+                                fixed point as the sweeps; red-black ordering, one slab only      */
+};
+
 /* step variants of fs3d_advance */
 enum {
     FS_STEP_REFERENCE = 0,   /* project, then self-advect: FluidSim::update (main.cpp:102-130)   */
@@ -113,7 +123,7 @@ typedef struct fs3d_config {
     int32_t advect_kernel;/* FS_ADVECT_*                                                          */
     int32_t advection;    /* FS_ADVECTION_*, the scheme of fs3d_advance (fs3d_update and
                              fs3d_semi_lagrange stay the reference's semi-Lagrange)                */
-    int32_t reserved;
+    int32_t solver;       /* FS_SOLVER_*                                                          */
     double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
     double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
     double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */
@@ -193,6 +203,9 @@ int fs3d_time_sweeps(fs3d_sim *sim, int n, double *ms);
 /* The projection loop of update() (main.cpp:105-111) under the configured
  * stopping rule; outputs may be NULL.                                       */
 int fs3d_project(fs3d_sim *sim, int *sweeps, double *metric);
+/* One V-cycle of FS_SOLVER_MULTIGRID on the current velocity (no counterpart in the
+ * reference; what fs3d_project repeats under that solver).                   */
+int fs3d_mg_vcycle(fs3d_sim *sim);
 /* L2 residual of the current field and max |div| (3_fluid/FluidSim.cpp:25-43). */
 int fs3d_residual(fs3d_sim *sim, double *l2, double *max_abs_div);
 /* semi_lagrange(t_step, snapshot...) (main.cpp:256-291) applied to a snapshot

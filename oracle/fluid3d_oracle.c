@@ -558,6 +558,191 @@ void o3_downsample_density(const O3 *o, int f, real *out) {
             }
 }
 
+/* ---- multigrid correction for the projection (not in the reference) -------------------------------
+ * The Gauss-Seidel visit of main.cpp:198-233 is a relaxation of the pressure Poisson equation written on
+ * the velocities: a visit subtracts the gradient of a one-cell pressure.  A V-cycle adds coarse
+ * corrections of the same form, so the fixed point is the one the sweeps alone converge to:
+ *   fine level   nu1 red-black sweeps; r = -div on Fluid cells; [coarse solve]; every face between two
+ *                Fluid cells gets  face -= alpha * (e_high - e_low)  with e the coarse error of the cell's
+ *                parent; nu2 red-black sweeps.
+ *   coarse level l (cells = 2x2x2 blocks of level l-1): weights of the low faces wx, wy, wz = the number of
+ *                open fine faces they gather (level 1: pairs of Fluid cells; deeper: sums of the child
+ *                weights), diag = sum of the six; red-black Gauss-Seidel on
+ *                diag*e - sum w_nb e_nb = r;  restriction = sum of the children's residuals, prolongation
+ *                = e_child += alpha * e_parent (piecewise constant; alpha makes up for the stiffness of
+ *                the summed operator).
+ * Everything is evaluated in a fixed order in the grid's precision, so a GPU version can match it bit for
+ * bit. */
+typedef struct MGLevel {
+    int nx, ny, nz;
+    real *wx, *wy, *wz, *diag, *e, *r;
+} MGLevel;
+
+static inline int64_t LI(const MGLevel *L, int x, int y, int z) { return ((int64_t)z * L->ny + y) * L->nx + x; }
+
+static void mg_level_alloc(MGLevel *L, int nx, int ny, int nz) {
+    const int64_t n = (int64_t)nx * ny * nz;
+    L->nx = nx; L->ny = ny; L->nz = nz;
+    L->wx = (real *)calloc(n, sizeof(real)); L->wy = (real *)calloc(n, sizeof(real)); L->wz = (real *)calloc(n, sizeof(real));
+    L->diag = (real *)calloc(n, sizeof(real)); L->e = (real *)calloc(n, sizeof(real)); L->r = (real *)calloc(n, sizeof(real));
+}
+static void mg_level_free(MGLevel *L) { free(L->wx); free(L->wy); free(L->wz); free(L->diag); free(L->e); free(L->r); }
+
+static inline real lw(const MGLevel *L, const real *w, int x, int y, int z) {   /* weight, 0 outside */
+    if (x < 0 || y < 0 || z < 0 || x >= L->nx || y >= L->ny || z >= L->nz) return 0;
+    return w[LI(L, x, y, z)];
+}
+
+static void mg_diag(MGLevel *L) {
+    for (int z = 0; z < L->nz; z++) for (int y = 0; y < L->ny; y++) for (int x = 0; x < L->nx; x++) {
+        const int64_t i = LI(L, x, y, z);
+        L->diag[i] = L->wx[i] + lw(L, L->wx, x + 1, y, z) + L->wy[i] + lw(L, L->wy, x, y + 1, z) + L->wz[i] +
+                     lw(L, L->wz, x, y, z + 1);
+    }
+}
+
+/* level 1 from the fine cell types */
+static void mg_weights_from_cells(const O3 *o, MGLevel *L) {
+    for (int z = 0; z < L->nz; z++) for (int y = 0; y < L->ny; y++) for (int x = 0; x < L->nx; x++) {
+        real wx = 0, wy = 0, wz = 0;
+        for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+            /* low-x face: fine cells (2x-1, 2y+a, 2z+b) and (2x, 2y+a, 2z+b) */
+            int fx = 2 * x, fy = 2 * y + a, fz = 2 * z + b;
+            if (fx >= 1 && fx < o->nx && fy < o->ny && fz < o->nz &&
+                o->s[IDX(o, fx, fy, fz)] == CELL_FLUID && o->s[IDX(o, fx - 1, fy, fz)] == CELL_FLUID) wx += 1;
+            fx = 2 * x + a; fy = 2 * y; fz = 2 * z + b;
+            if (fy >= 1 && fy < o->ny && fx < o->nx && fz < o->nz &&
+                o->s[IDX(o, fx, fy, fz)] == CELL_FLUID && o->s[IDX(o, fx, fy - 1, fz)] == CELL_FLUID) wy += 1;
+            fx = 2 * x + a; fy = 2 * y + b; fz = 2 * z;
+            if (fz >= 1 && fz < o->nz && fx < o->nx && fy < o->ny &&
+                o->s[IDX(o, fx, fy, fz)] == CELL_FLUID && o->s[IDX(o, fx, fy, fz - 1)] == CELL_FLUID) wz += 1;
+        }
+        const int64_t i = LI(L, x, y, z);
+        L->wx[i] = wx; L->wy[i] = wy; L->wz[i] = wz;
+    }
+    mg_diag(L);
+}
+
+static void mg_weights_from_level(const MGLevel *F, MGLevel *L) {
+    for (int z = 0; z < L->nz; z++) for (int y = 0; y < L->ny; y++) for (int x = 0; x < L->nx; x++) {
+        real wx = 0, wy = 0, wz = 0;
+        for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+            wx += lw(F, F->wx, 2 * x, 2 * y + a, 2 * z + b);
+            wy += lw(F, F->wy, 2 * x + a, 2 * y, 2 * z + b);
+            wz += lw(F, F->wz, 2 * x + a, 2 * y + b, 2 * z);
+        }
+        const int64_t i = LI(L, x, y, z);
+        L->wx[i] = wx; L->wy[i] = wy; L->wz[i] = wz;
+    }
+    mg_diag(L);
+}
+
+static inline real le(const MGLevel *L, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= L->nx || y >= L->ny || z >= L->nz) return 0;
+    return L->e[LI(L, x, y, z)];
+}
+
+/* sum over the six neighbours of weight * e, in the order x-, x+, y-, y+, z-, z+ */
+static inline real mg_offdiag(const MGLevel *L, int x, int y, int z) {
+    const int64_t i = LI(L, x, y, z);
+    real a = 0;
+    a += L->wx[i] * le(L, x - 1, y, z);
+    a += lw(L, L->wx, x + 1, y, z) * le(L, x + 1, y, z);
+    a += L->wy[i] * le(L, x, y - 1, z);
+    a += lw(L, L->wy, x, y + 1, z) * le(L, x, y + 1, z);
+    a += L->wz[i] * le(L, x, y, z - 1);
+    a += lw(L, L->wz, x, y, z + 1) * le(L, x, y, z + 1);
+    return a;
+}
+
+static void mg_smooth(MGLevel *L, int sweeps) {
+    for (int it = 0; it < sweeps; it++)
+        for (int colour = 0; colour < 2; colour++)
+            for (int z = 0; z < L->nz; z++) for (int y = 0; y < L->ny; y++) for (int x = 0; x < L->nx; x++) {
+                if (((x + y + z) & 1) != colour) continue;
+                const int64_t i = LI(L, x, y, z);
+                if (L->diag[i] > 0) L->e[i] = (L->r[i] + mg_offdiag(L, x, y, z)) / L->diag[i];
+            }
+}
+
+/* r of level C = sum over the 8 children of (r - (diag*e - offdiag)) of level F, children in z, y, x order */
+static void mg_restrict(const MGLevel *F, MGLevel *C) {
+    for (int z = 0; z < C->nz; z++) for (int y = 0; y < C->ny; y++) for (int x = 0; x < C->nx; x++) {
+        real acc = 0;
+        for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+            const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;
+            if (fx >= F->nx || fy >= F->ny || fz >= F->nz) continue;
+            const int64_t i = LI(F, fx, fy, fz);
+            if (F->diag[i] > 0) acc += F->r[i] - (F->diag[i] * F->e[i] - mg_offdiag(F, fx, fy, fz));
+        }
+        C->r[LI(C, x, y, z)] = acc;
+    }
+}
+
+static void mg_prolong(MGLevel *F, const MGLevel *C, real alpha) {
+    for (int z = 0; z < F->nz; z++) for (int y = 0; y < F->ny; y++) for (int x = 0; x < F->nx; x++) {
+        const int64_t i = LI(F, x, y, z);
+        if (F->diag[i] > 0) F->e[i] += alpha * C->e[LI(C, x / 2, y / 2, z / 2)];
+    }
+}
+
+static void mg_coarse_cycle(MGLevel *L, int l, int nlev, int nu1, int nu2, int nu_bottom, real alpha) {
+    memset(L[l].e, 0, (int64_t)L[l].nx * L[l].ny * L[l].nz * sizeof(real));
+    if (l == nlev - 1) { mg_smooth(&L[l], nu_bottom); return; }
+    mg_smooth(&L[l], nu1);
+    mg_restrict(&L[l], &L[l + 1]);
+    mg_coarse_cycle(L, l + 1, nlev, nu1, nu2, nu_bottom, alpha);
+    mg_prolong(&L[l], &L[l + 1], alpha);
+    mg_smooth(&L[l], nu2);
+}
+
+/* One V-cycle on the velocity field.  nlev_max limits the depth (<= 0: down to a level of at most 4 cells
+ * along its shortest axis). */
+void o3_mg_vcycle(O3 *o, int nu1, int nu2, int nu_bottom, real alpha, int nlev_max) {
+    MGLevel L[16];
+    int nlev = 0, nx = o->nx, ny = o->ny, nz = o->nz;
+    while (nlev < 16 && (nlev_max <= 0 || nlev < nlev_max)) {
+        nx = (nx + 1) / 2; ny = (ny + 1) / 2; nz = (nz + 1) / 2;
+        mg_level_alloc(&L[nlev], nx, ny, nz);
+        if (nlev == 0) mg_weights_from_cells(o, &L[0]); else mg_weights_from_level(&L[nlev - 1], &L[nlev]);
+        nlev++;
+        if (nx <= 4 || ny <= 4 || nz <= 4) break;
+    }
+    for (int k = 0; k < nu1; k++) { o3_rb_halfsweep(o, 0, R(1.0)); o3_rb_halfsweep(o, 1, R(1.0)); }
+    /* residual of the Fluid cells, summed over the children of every level-1 cell (z, y, x order) */
+    {
+        MGLevel *C = &L[0];
+        for (int z = 0; z < C->nz; z++) for (int y = 0; y < C->ny; y++) for (int x = 0; x < C->nx; x++) {
+            real acc = 0;
+            for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+                const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;
+                if (fx < 1 || fy < 1 || fz < 1 || fx >= o->nx - 1 || fy >= o->ny - 1 || fz >= o->nz - 1) continue;
+                const int64_t i = IDX(o, fx, fy, fz);
+                if (o->s[i] != CELL_FLUID) continue;
+                const real div = (o->u[IDX(o, fx + 1, fy, fz)] - o->u[i]) + (o->v[IDX(o, fx, fy + 1, fz)] - o->v[i]) +
+                                 (o->w[IDX(o, fx, fy, fz + 1)] - o->w[i]);
+                acc += -div;
+            }
+            C->r[LI(C, x, y, z)] = acc;
+        }
+    }
+    mg_coarse_cycle(L, 0, nlev, nu1, nu2, nu_bottom, alpha);
+    /* faces between two Fluid cells take the gradient of the level-1 error of their cells' parents */
+    {
+        const MGLevel *C = &L[0];
+        FOR_INTERIOR(o) {
+            const int64_t i = IDX(o, x, y, z);
+            if (o->s[i] != CELL_FLUID) continue;
+            const real eh = C->e[LI(C, x / 2, y / 2, z / 2)];
+            if (o->s[IDX(o, x - 1, y, z)] == CELL_FLUID) o->u[i] -= alpha * (eh - C->e[LI(C, (x - 1) / 2, y / 2, z / 2)]);
+            if (o->s[IDX(o, x, y - 1, z)] == CELL_FLUID) o->v[i] -= alpha * (eh - C->e[LI(C, x / 2, (y - 1) / 2, z / 2)]);
+            if (o->s[IDX(o, x, y, z - 1)] == CELL_FLUID) o->w[i] -= alpha * (eh - C->e[LI(C, x / 2, y / 2, (z - 1) / 2)]);
+        }
+    }
+    for (int k = 0; k < nu2; k++) { o3_rb_halfsweep(o, 0, R(1.0)); o3_rb_halfsweep(o, 1, R(1.0)); }
+    for (int l = 0; l < nlev; l++) mg_level_free(&L[l]);
+}
+
 /* Reflection of the unprojected field about the projected one (Zehnder et
  * al. 2018, Alg. 1): out = 2*proj - tilde, on every element. */
 void o3_reflect(int64_t n, const real *proj, const real *tilde, real *out) {

@@ -62,6 +62,7 @@ def _lib(dtype):
     lib.o3_advect.argtypes = [P, real] + [P] * 11 + [C.c_int]
     lib.o3_reflect.argtypes = [C.c_int64, P, P, P]
     lib.o3_maccormack.argtypes = [P, real] + [P] * 15
+    lib.o3_mg_vcycle.argtypes = [P, C.c_int, C.c_int, C.c_int, real, C.c_int]
     lib.o3_vorticity.argtypes = [P, P]
     lib.o3_vorticity.restype = C.c_double
     lib.o3_diagnostics.argtypes = [P, C.POINTER(C.c_double)]
@@ -208,6 +209,10 @@ class Oracle3D:
         self.lib.o3_maccormack(self.h, dt, *[_ptr(a) for a in q], *[_ptr(a) for a in vel], *[_ptr(a) for a in f],
                                *[_ptr(a) for a in out])
         return out
+
+    def mg_vcycle(self, nu1=2, nu2=2, nu_bottom=20, alpha=2.0, nlev_max=0):
+        """One multigrid V-cycle on the velocity field (see o3_mg_vcycle)."""
+        self.lib.o3_mg_vcycle(self.h, nu1, nu2, nu_bottom, alpha, nlev_max)
 
     def vorticity(self):
         """(|curl u| field, sum of |curl u|^2)"""

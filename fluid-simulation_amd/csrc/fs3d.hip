@@ -637,6 +637,7 @@ int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
 // ---- multigrid V-cycle (fs_mg3d.hpp) ---------------------------------------------------------------
 constexpr int kMgNu1 = 2, kMgNu2 = 2, kMgBottom = 30;
 constexpr double kMgAlpha = 2.0;
+constexpr int64_t kMgSmallCells = 4096;   // levels up to this size run inside one workgroup
 
 template <typename T>
 MgLevel<T> mg_level(const Part::MgRaw& r) {
@@ -689,6 +690,15 @@ template <typename T>
 int mg_coarse_cycle(fs3d_sim* s, Part& p, size_t l) {
     const Part::MgRaw& r = p.mg[l];
     dim3 b(64, 4, 1), g(div_up(r.nx, 64), div_up(r.ny, 4), r.nz);
+    if ((int64_t)r.nx * r.ny * r.nz <= kMgSmallCells) {   // this level and everything below it in one workgroup
+        MgSmall<T, 8> S;
+        S.n = 0;
+        for (size_t k = l; k < p.mg.size() && S.n < 8; ++k) S.L[S.n++] = mg_level<T>(p.mg[k]);
+        if ((size_t)S.n == p.mg.size() - l) {
+            hipLaunchKernelGGL((k_mg_small_cycle<T, 8>), dim3(1), dim3(1024), 0, s->stream, S, kMgNu1, kMgNu2, kMgBottom, (T)kMgAlpha);
+            return FS_OK;
+        }
+    }
     SIM_HIP(hipMemsetAsync(r.a[4], 0, (size_t)r.nx * r.ny * r.nz * sizeof(T), s->stream));
     if (l + 1 == p.mg.size()) return mg_smooth<T>(s, r, kMgBottom);
     FS_TRY(mg_smooth<T>(s, r, kMgNu1));

@@ -169,6 +169,66 @@ __global__ void k_mg_apply(Grid g, T* __restrict__ u, T* __restrict__ v, T* __re
     if (fl & FL_ZM) w[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, y / 2, (z - 1) / 2)]);
 }
 
+// The levels of at most a few thousand cells in one workgroup: the sub-cycle below a level costs ~80
+// launches of a few microseconds each when every colour of every sweep is a kernel of its own.  Same
+// operations in the same per-value order as the per-level kernels; colours and stages are separated by
+// workgroup barriers.
+template <typename T, int MAXL>
+struct MgSmall { int n; MgLevel<T> L[MAXL]; };
+
+template <typename T, int MAXL>
+__global__ void __launch_bounds__(1024)
+k_mg_small_cycle(MgSmall<T, MAXL> S, int nu1, int nu2, int nu_bottom, T alpha) {
+    const int tid = threadIdx.x;
+    auto cells = [](const MgDims& d) { return d.nx * d.ny * d.nz; };
+    auto smooth = [&](const MgLevel<T>& L, int sweeps) {
+        const int n = cells(L.d);
+        for (int it = 0; it < sweeps; ++it)
+            for (int colour = 0; colour < 2; ++colour) {
+                for (int idx = tid; idx < n; idx += 1024) {
+                    const int x = idx % L.d.nx, y = (idx / L.d.nx) % L.d.ny, z = idx / (L.d.nx * L.d.ny);
+                    if (((x + y + z) & 1) != colour) continue;
+                    const T dg = L.diag[idx];
+                    if (dg > (T)0) L.e[idx] = (L.r[idx] + mg_offdiag(L, x, y, z)) / dg;
+                }
+                __syncthreads();
+            }
+    };
+    for (int l = 0; l < S.n; ++l) {
+        const MgLevel<T>& L = S.L[l];
+        for (int idx = tid; idx < cells(L.d); idx += 1024) L.e[idx] = 0;
+        __syncthreads();
+        if (l == S.n - 1) { smooth(L, nu_bottom); break; }
+        smooth(L, nu1);
+        const MgLevel<T>& C = S.L[l + 1];
+        for (int idx = tid; idx < cells(C.d); idx += 1024) {
+            const int x = idx % C.d.nx, y = (idx / C.d.nx) % C.d.ny, z = idx / (C.d.nx * C.d.ny);
+            T acc = 0;
+            for (int c = 0; c < 2; ++c)
+                for (int b = 0; b < 2; ++b)
+                    for (int a = 0; a < 2; ++a) {
+                        const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;
+                        if (fx >= L.d.nx || fy >= L.d.ny || fz >= L.d.nz) continue;
+                        const int64_t i = mgi(L.d, fx, fy, fz);
+                        const T dg = L.diag[i];
+                        if (dg > (T)0) acc += L.r[i] - (dg * L.e[i] - mg_offdiag(L, fx, fy, fz));
+                    }
+            C.r[idx] = acc;
+        }
+        __syncthreads();
+    }
+    for (int l = S.n - 2; l >= 0; --l) {
+        const MgLevel<T>& L = S.L[l];
+        const MgLevel<T>& C = S.L[l + 1];
+        for (int idx = tid; idx < cells(L.d); idx += 1024) {
+            const int x = idx % L.d.nx, y = (idx / L.d.nx) % L.d.ny, z = idx / (L.d.nx * L.d.ny);
+            if (L.diag[idx] > (T)0) L.e[idx] += alpha * C.e[mgi(C.d, x / 2, y / 2, z / 2)];
+        }
+        __syncthreads();
+        smooth(L, nu2);
+    }
+}
+
 #undef FS_MG_CELL
 
 }  // namespace fsamd

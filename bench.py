@@ -47,6 +47,7 @@ def parse():
                     help="sweeps: red-black Gauss-Seidel only (the north star's solver); multigrid: V-cycles around them")
     ap.add_argument("--local-slabs", type=int, default=1,
                     help="cut each rank's planes into this many z-slabs on its own GPU (rehearses the slab path)")
+    ap.add_argument("--no-multigrid-leg", action="store_true", help="skip the extra run with the multigrid solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--max-iters", type=int, default=1000)
@@ -86,6 +87,34 @@ def cpu_baseline(n, sweeps_per_step, sample_sweeps=None):
                   f"({t_adv:.2f} s) of the same {n}^3 vortex ring, scaled to {sweeps_per_step:.0f} sweeps per step",
         "ms_per_sweep": t_sweep * 1e3,
     }
+
+
+def multigrid_leg(fs, scenes, a, nx, ny, nz, device):
+    """The same steps on a fresh state with FS_SOLVER_MULTIGRID (V-cycles around the same red-black sweeps, same
+    stopping rule): reported beside the headline value, which stays on the sweeps-only solver."""
+    sim = fs.FluidSim3D(nx, ny, nz, device=device, dtype=fs.F64 if a.dtype == "f64" else fs.F32,
+                        stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters, check_every=a.check_every,
+                        omega=a.omega, step_mode=a.step_mode, solver=1, buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
+    scene_init, scene_step = scenes.SCENES[a.scene]
+    scene_init(sim)
+    it = 0
+    for _ in range(a.warmup):
+        scene_step(sim, it); it += 1
+        sim.advance(DT)
+    sim.synchronize()
+    t0 = time.perf_counter()
+    sweeps = 0
+    for _ in range(a.steps):
+        scene_step(sim, it); it += 1
+        sim.advance(DT)
+        sweeps += sim.stats().sweeps_step
+    sim.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = sim.stats()
+    sim.close()
+    return {"value": nx * ny * nz / (elapsed / a.steps) / 1e6, "unit": "Mcells/s", "ms_per_step": elapsed / a.steps * 1e3,
+            "sweeps_per_step": sweeps / a.steps, "last_residual": st.metric,
+            "note": "V(2,2) cycles, 2x2x2 coarsening, piecewise-constant transfer, a cycle counted as 4 sweeps"}
 
 
 def main():
@@ -203,6 +232,8 @@ def main():
                     line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
             except Exception:
                 pass
+        if world == 1 and a.solver == "sweeps" and a.local_slabs == 1 and not a.no_multigrid_leg:
+            line["solver_multigrid"] = multigrid_leg(fs, scenes, a, nx, ny, nz, local_rank)
         if world == 1 and not a.no_cpu_baseline and a.scene == "vortex_ring" and not a.grid and a.dtype == "f32":
             line["cpu_baseline"] = cpu_baseline(n, sweeps_per_step)
         print(json.dumps(line), flush=True)

@@ -71,6 +71,8 @@ struct fs3d_sim {
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;        // halo traffic of the one-pass sweep, overlapped with its interior
     hipEvent_t ev_bnd = nullptr, ev_comm = nullptr, ev_b = nullptr;
+    int mg_backoff[2] = {0, 0};  // projections to wait before plain sweeps are tried again under the multigrid solver
+    int mg_fails[2] = {0, 0};    // consecutive failed tries
     bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
@@ -756,8 +758,30 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
     int it = 0;
     double metric = 0;
     if (c.solver == FS_SOLVER_MULTIGRID) {
-        // V-cycles; the stopping rule is evaluated after every cycle, a cycle counts as its fine sweeps
-        for (;;) {
+        // V-cycles; the stopping rule is evaluated after every cycle, a cycle counts as its fine sweeps.
+        // A cycle costs more than four sweeps, so where sweeps alone may do (the same projection of the
+        // previous step needed at most two of them, or a single cycle: worth a try now and then) up to
+        // two plain sweeps are tried first.
+        bool done = false;
+        int& backoff = s->mg_backoff[slot & 1];
+        const int hint = s->sweep_hint[slot & 1];
+        const bool try_plain = c.stop_mode == FS_STOP_L2_RESIDUAL && c.max_iters > 2 &&
+                               (hint <= 2 || (hint <= kMgNu1 + kMgNu2 + 2 && backoff == 0));
+        if (backoff > 0) --backoff;
+        if (try_plain) {
+            for (int k = 0; k < 2 && !done; ++k) {
+                FS_TRY(sweep_once<T>(s));
+                ++it;
+                FS_TRY(residual<T>(s, &metric, nullptr, false));
+                metric /= s->resid_dt;
+                done = !(metric > c.tol);
+            }
+            // a failed try is paid for by waiting: 2, 4, 8, 8, ... projections
+            int& fails = s->mg_fails[slot & 1];
+            fails = done ? 0 : std::min(fails + 1, 3);
+            if (!done) backoff = 1 << fails;
+        }
+        while (!done) {
             FS_TRY(mg_vcycle<T>(s));
             it += kMgNu1 + kMgNu2;
             if (c.stop_mode == FS_STOP_L2_RESIDUAL) {
@@ -1349,6 +1373,8 @@ int fs3d_reset(fs3d_sim* s) {
     s->curv = 0;
     s->curd = 0;
     s->sweep_hint[0] = s->sweep_hint[1] = 1;
+    s->mg_backoff[0] = s->mg_backoff[1] = 0;
+    s->mg_fails[0] = s->mg_fails[1] = 0;
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
     *s->hoob = 0;
     s->stats = fs3d_stats{};

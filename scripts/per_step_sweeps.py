@@ -10,7 +10,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ces = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 0, 8]
 for ce in ces:
     sim = fs.FluidSim3D(n, n, n, stop_mode=fs.STOP_L2_RESIDUAL, tol=1e-6, max_iters=1000,
-                        check_every=ce, step_mode=1)
+                        check_every=ce, step_mode=1, solver=1 if 'mg' in sys.argv else 0)
     init, per_step = scenes.SCENES["vortex_ring"]
     init(sim)
     out = []

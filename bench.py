@@ -132,7 +132,12 @@ def main():
     import fsamd_loader
     fs = fsamd_loader.load()
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank
+    if os.environ.get("FSAMD_BENCH_SHARE_GPU") == "1":
+        # rehearsal of the launch line on a machine with fewer GPUs than ranks (needs a transport that accepts
+        # several ranks per device, see tests/fake_rccl); never a measurement
+        device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
     comm_id = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,7 +149,7 @@ def main():
     import fluid_simulation_amd.scenes as scenes
     n = a.n or (256 if world == 1 else 512)
     nx, ny, nz = (int(v) for v in a.grid.split(",")) if a.grid else (n, n, n)
-    sim = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=world, comm_id=comm_id, device=local_rank,
+    sim = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=world, comm_id=comm_id, device=device,
                         dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
                         check_every=a.check_every, omega=a.omega, step_mode=a.step_mode, local_slabs=a.local_slabs, solver=1 if a.solver == "multigrid" else 0,
@@ -233,7 +238,7 @@ def main():
             except Exception:
                 pass
         if world == 1 and a.solver == "sweeps" and a.local_slabs == 1 and not a.no_multigrid_leg:
-            line["solver_multigrid"] = multigrid_leg(fs, scenes, a, nx, ny, nz, local_rank)
+            line["solver_multigrid"] = multigrid_leg(fs, scenes, a, nx, ny, nz, device)
         if world == 1 and not a.no_cpu_baseline and a.scene == "vortex_ring" and not a.grid and a.dtype == "f32":
             line["cpu_baseline"] = cpu_baseline(n, sweeps_per_step)
         print(json.dumps(line), flush=True)

@@ -1202,6 +1202,7 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     std::string why;
     if (nx < 3 || ny < 3 || nz < 3 || !config_ok(&cfg, &why) || rank < 0 || rank >= nranks) return FS_EINVAL;
     if (cfg.ordering == FS_ORDER_LEXICOGRAPHIC && (nranks > 1 || cfg.local_slabs > 1)) return FS_EINVAL;
+    if (cfg.solver == FS_SOLVER_MULTIGRID && nranks > 1) return FS_EINVAL;
     fs3d_sim* s = new (std::nothrow) fs3d_sim();
     if (!s) return FS_ENOMEM;
     *out = s;   // handed back even on failure so that the caller can read the error text, then destroy
@@ -1391,6 +1392,8 @@ int fs3d_set_config(fs3d_sim* s, const fs3d_config* c) {
         return set_err(s, FS_EINVAL, "dtype and local_slabs are fixed at creation");
     if (c->ordering == FS_ORDER_LEXICOGRAPHIC && s->nparts_global > 1)
         return set_err(s, FS_EINVAL, "lexicographic order needs a single slab");
+    if (c->solver == FS_SOLVER_MULTIGRID && s->nparts_global > 1)
+        return set_err(s, FS_EINVAL, "the multigrid solver needs a single slab");
     const int dev = s->cfg.device;
     s->cfg = *c;
     s->cfg.device = dev;

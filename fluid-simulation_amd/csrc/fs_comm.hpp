@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <string>
 
 namespace fsamd {
@@ -32,10 +33,17 @@ struct Rccl {
         static std::string failure;
         if (!tried) {
             tried = true;
+            // FSAMD_RCCL_LIBRARY names the library to bind instead of the system's RCCL (a site build, or the
+            // shared-memory stand-in the tests use to run several ranks on one GPU); if set it must load.
+            const char* forced = getenv("FSAMD_RCCL_LIBRARY");
             const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-            for (const char* n : names) {
-                inst.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-                if (inst.handle) break;
+            if (forced && *forced) {
+                inst.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            } else {
+                for (const char* n : names) {
+                    inst.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                    if (inst.handle) break;
+                }
             }
             if (!inst.handle) {
                 failure = std::string("cannot load RCCL: ") + dlerror();

@@ -1,0 +1,95 @@
+"""Scenarios run identically by a single-domain simulation and by the ranks of a multi-process z-slab run; each
+returns a dict of owned-plane fields (3D arrays, concatenated over ranks by the caller) and scalars (which must
+agree on every rank)."""
+import numpy as np
+
+from tests.util3d import random_cells, random_field
+
+
+def _create(fs, nx, ny, nz, rank, nranks, comm_id, seed=9, scale=20.0, masks=True, **cfg):
+    g = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=nranks, comm_id=comm_id, device=0, **cfg)
+    rng = np.random.default_rng(seed)
+    shape = (nz, ny, nx)
+    z0, z1 = g.z0, g.z1
+    if masks:
+        g.set_cell_types(random_cells(shape, rng)[z0:z1])
+    fields = [random_field(shape, rng, np.float32, scale if k < 3 else 1.0) for k in range(4)]
+    fields[3] = np.abs(fields[3])
+    for k in range(4):
+        g.set_field(k, fields[k][z0:z1])
+    return g
+
+
+def _snapshot(g, rec, tag):
+    for k, name in enumerate("uvwd"):
+        rec[f"{tag}_{name}"] = g.get_field(k)
+    st = g.stats()
+    rec[f"{tag}_sweeps"] = st.sweeps_step
+    rec[f"{tag}_metric"] = st.metric
+
+
+def steps_l1(fs, sweep_kernel=0, **kw):
+    """Both step modes with the reference's stopping rule (L1 change of one sweep)."""
+    g = _create(fs, 28, 18, 23, sweep_kernel=sweep_kernel, **kw)
+    rec = {}
+    for mode in (0, 1):
+        g.set_config(step_mode=mode, tol=1.0)
+        for step in range(2):
+            g.advance(0.02)
+            _snapshot(g, rec, f"m{mode}s{step}")
+    l2, mx = g.residual()
+    rec["res_l2"], rec["res_max"] = l2, mx
+    g.close()
+    return rec
+
+
+def steps_two_pass(fs, **kw):
+    return steps_l1(fs, sweep_kernel=1, **kw)
+
+
+def steps_residual(fs, **kw):
+    """Reflection steps stopped by the all-reduced L2 residual with the adaptive check schedule, then the
+    diagnostics reductions and a restart file written by every rank."""
+    g = _create(fs, 40, 22, 37, seed=4, scale=6.0, stop_mode=fs.STOP_L2_RESIDUAL, tol=2e-3, max_iters=60,
+                check_every=0, step_mode=1, **kw)
+    rec = {}
+    for step in range(3):
+        g.advance(0.02)
+        _snapshot(g, rec, f"s{step}")
+    d = g.diagnostics()
+    rec["diag"] = np.array([getattr(d, f[0]) for f in d._fields_], dtype=np.float64)
+    rec["vort"] = g.vorticity()
+    g.close()
+    return rec
+
+
+def steps_maccormack(fs, **kw):
+    g = _create(fs, 28, 18, 23, advection=1, step_mode=1, tol=1.0, **kw)
+    rec = {}
+    for step in range(2):
+        g.advance(0.02)
+        _snapshot(g, rec, f"s{step}")
+    g.close()
+    return rec
+
+
+def vortex_ring(fs, **kw):
+    """The benchmark scene (emitter in global coordinates, density re-stamp) at a small size."""
+    n = 48
+    g = fs.FluidSim3D(n, n, n, device=0, stop_mode=fs.STOP_L2_RESIDUAL, tol=1e-4, max_iters=40, check_every=0,
+                      step_mode=1, **kw)
+    g.sphere_influence(n / 10.0)
+    rec = {}
+    for it in range(3):
+        g.fill_sphere_influence(n / 10.0, it)
+        g.advance(1.0 / 30.0)
+        _snapshot(g, rec, f"s{it}")
+    g.close()
+    return rec
+
+
+SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, steps_maccormack, vortex_ring)}
+
+
+def run(fs, name, rank=0, nranks=1, comm_id=None):
+    return SCENARIOS[name](fs, rank=rank, nranks=nranks, comm_id=comm_id)

@@ -59,3 +59,15 @@ def test_missing_library_fails_loudly(fsamd, tmp_path):
 
 def test_version_string(fsamd):
     assert b"gfx950" in fsamd.load_library().fsamd_version()
+
+
+def test_rccl_stand_in_exports_what_the_library_binds():
+    # the shared-memory transport of tests/fake_rccl must offer every symbol fs_comm.hpp looks up
+    import ctypes
+    path = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(path):
+        pytest.skip("tests/fake_rccl not built")
+    lib = ctypes.CDLL(path)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart",
+                 "ncclGroupEnd", "ncclAllReduce", "ncclGetErrorString"):
+        assert hasattr(lib, name), name

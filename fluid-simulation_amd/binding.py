@@ -27,6 +27,7 @@ CELL_FLUID, CELL_OBJECT, CELL_STATIC_FLUID = 0, 1, 2
 FIELD_U, FIELD_V, FIELD_W, FIELD_DENSITY, FIELD_DIVERGENCE, FIELD_VORTICITY = range(6)
 ORDER_RED_BLACK, ORDER_LEXICOGRAPHIC = 0, 1
 STOP_FIXED, STOP_L1_CHANGE, STOP_L2_RESIDUAL = 0, 1, 2
+CHECK_ADAPTIVE, CHECK_DEFERRED = 0, -1
 STEP_REFERENCE, STEP_REFLECTION = 0, 1
 SWEEP_FUSED, SWEEP_TWO_PASS, SWEEP_FUSED_LDS = 0, 1, 2
 ADVECT_TILED, ADVECT_DIRECT = 0, 1

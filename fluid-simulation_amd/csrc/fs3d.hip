@@ -61,6 +61,9 @@ struct Part {
     void* recv_lo = nullptr;   // staging for the interface w plane from the lower / upper rank
     void* recv_hi = nullptr;
     double* partials = nullptr;
+    double* adv_part = nullptr;   // per-workgroup residual partials of an advection that verifies a projection
+    size_t adv_cap = 0;           // pairs it holds
+    int adv_blocks = 0;           // pairs the last such advection wrote
     int own_planes() const { return z1 - z0; }
 };
 
@@ -73,6 +76,9 @@ struct fs3d_sim {
     hipEvent_t ev_bnd = nullptr, ev_comm = nullptr, ev_b = nullptr;
     int mg_backoff[2] = {0, 0};  // projections to wait before plain sweeps are tried again under the multigrid solver
     int mg_fails[2] = {0, 0};    // consecutive failed tries
+    int spec_backoff[2] = {0, 0};   // deferred residual check: projections to wait after a failed one,
+    int spec_fails[2] = {0, 0};     // consecutive failures,
+    int spec_streak[2] = {0, 0};    // consecutive successes with more than one sweep
     bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
@@ -141,6 +147,7 @@ void free_parts(fs3d_sim* s) {
         (void)hipFree(p.cells); (void)hipFree(p.flags);
         (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
         (void)hipFree(p.partials);
+        (void)hipFree(p.adv_part);
     }
     s->parts.clear();
 }
@@ -567,17 +574,24 @@ int oob_status(fs3d_sim* s) {
     return FS_OK;
 }
 
-int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
+// Queues, on the main stream, the combination of the per-part pairs (across ranks too) and their copy to
+// the host mirror.
+int queue_reduction(fs3d_sim* s, bool want_max) {
     FS_TRY(join_halos(s));   // one stream at a time on the communicator
     double* comb = s->dres + 2 * s->nlocal;
     hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
     SIM_HIP(hipGetLastError());
     if (s->nranks > 1) {
         FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm, s->stream), "ncclAllReduce"));
-        if (mx)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
+        if (want_max)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
             FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
     }
     SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    return FS_OK;
+}
+
+int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
+    FS_TRY(queue_reduction(s, mx != nullptr));
     FS_TRY(quiesce(s));
     if (sum) *sum = s->hres[0];
     if (mx) *mx = s->hres[1];
@@ -742,21 +756,33 @@ int sweep_with_change(fs3d_sim* s, double* change) {
 }
 
 // The loop of update() (main.cpp:105-111) under the configured stopping rule.
-// check_every == 0 selects the adaptive schedule: the metric is first evaluated one sweep before the
-// count the same projection of the previous step needed, then after every sweep (consecutive steps need
-// nearly the same number of sweeps, so this costs one or two evaluations and stops at the exact sweep).
+// check_every == 0 selects the adaptive schedule: the metric is evaluated from one sweep before the count the
+// same projection of the previous step needed, then after every sweep (consecutive steps need nearly the
+// same number of sweeps, so this costs one or two evaluations and stops at the exact sweep), and twice on
+// the way there.
+// unchecked > 0: exactly that many sweeps and no evaluation (the caller verifies the stopping rule afterwards);
+// resume_from > 0: the projection already holds that many sweeps and goes on, evaluating after every sweep.
 template <typename T>
-int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
+int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int unchecked = 0, int resume_from = 0) {
     // the interior of a one-pass sweep reads no halo plane: let the exchange run beside it
     const bool one_pass = s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
     FS_TRY(prepare(s, HALO_VEL, one_pass));
     const fs3d_config& c = s->cfg;
-    const bool adaptive = c.check_every == 0;
+    const bool adaptive = c.check_every <= 0;
     const int every = std::max(1, c.check_every);
-    const int first = adaptive ? std::max(1, s->sweep_hint[slot & 1] - 1) : 1;
-    const int coarse = std::max(8, first / 4);   // sparse early checks, so that a stale hint cannot cost much
-    int it = 0;
+    const int first = resume_from > 0 ? resume_from + 1 : adaptive ? std::max(1, s->sweep_hint[slot & 1] - 1) : 1;
+    // two early evaluations, at a quarter and at half of the expected count: a count that collapses (the step
+    // after a start-up transient) is then found within a step or two, and a stale hint cannot cost much
+    const int early1 = first / 4, early2 = first / 2;
+    int it = resume_from;
     double metric = 0;
+    if (unchecked > 0) {
+        for (int k = 0; k < unchecked; ++k) FS_TRY(sweep_once<T>(s));
+        s->stats.sweeps = unchecked;
+        s->stats.sweeps_step += unchecked;
+        halos_after_sweeps(s);
+        return FS_OK;
+    }
     if (c.solver == FS_SOLVER_MULTIGRID) {
         // V-cycles; the stopping rule is evaluated after every cycle, a cycle counts as its fine sweeps.
         // A cycle costs more than four sweeps, so where sweeps alone may do (the same projection of the
@@ -793,7 +819,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
         }
     } else
     for (;;) {
-        const bool check = (adaptive ? (it + 1 >= first || (it + 1) % coarse == 0) : ((it + 1) % every == 0)) ||
+        const bool check = (adaptive ? (it + 1 >= first || it + 1 == early1 || it + 1 == early2) : ((it + 1) % every == 0)) ||
                            (it + 1 >= c.max_iters);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
             FS_TRY(sweep_with_change<T>(s, &metric));
@@ -812,7 +838,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
     // a projection that ran into the cap says nothing about the next one: start checking at once
     s->sweep_hint[slot & 1] = (it >= c.max_iters && metric > c.tol) ? 1 : it;
     s->stats.sweeps = it;
-    s->stats.sweeps_step += it;
+    s->stats.sweeps_step += it - resume_from;
     s->stats.metric = metric;
     halos_after_sweeps(s);
     if (sweeps_out) *sweeps_out = it;
@@ -825,7 +851,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0) {
 // generation's velocity into the other generation, then swaps generations.
 template <typename T, typename OFF, bool SLAB>
 int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, int cv, int ov, int cd, int od, T t_step,
-                  int density_mode, bool copy_to_tmp, bool reflect) {
+                  int density_mode, bool copy_to_tmp, bool reflect, bool with_res) {
     // the owned planes, shell included, so that the new generation is complete
     const int zb = p.H, ze = p.H + p.own_planes();
     T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
@@ -833,6 +859,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
     T* c2 = copy_to_tmp ? (T*)p.tmp[2] : nullptr;
     const T *U = F<T>(p, cv, 0), *V = F<T>(p, cv, 1), *W = F<T>(p, cv, 2);
     if (s->cfg.advect_kernel == FS_ADVECT_DIRECT) {
+        if (with_res) return set_err(s, FS_ESTATE, "only the staged advection kernel evaluates the residual");
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
         hipLaunchKernelGGL((k_advect<T, OFF, SLAB>), g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0),
                            F<T>(p, ov, 1), F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb,
@@ -847,8 +874,21 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus);
         const int zchunk = div_up(ze - zb, nchunks);
         dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), div_up(ze - zb, zchunk));
+        double* res_part = nullptr;
+        if (with_res) {
+            const size_t blocks = (size_t)g.x * g.y * g.z;
+            if (blocks > p.adv_cap) {
+                (void)hipFree(p.adv_part);
+                p.adv_part = nullptr; p.adv_cap = 0;
+                SIM_HIP(hipMalloc((void**)&p.adv_part, blocks * 2 * sizeof(double)));
+                p.adv_cap = blocks;
+            }
+            p.adv_blocks = (int)blocks;
+            res_part = p.adv_part;
+        }
         hipLaunchKernelGGL(kern, g, b, lds, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0), F<T>(p, ov, 1),
-                           F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob);
+                           F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob,
+                           res_part);
         return FS_OK;
     };
     if (reflect) return go(k_advect_tiled<T, OFF, true, SLAB, true>, AdvTile<T, true>::lds_bytes());
@@ -858,8 +898,11 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
 
 // copy_to_tmp: the new velocity is also written to the scratch fields (the unprojected half-step
 // field the reflection needs later).
+// res_sum: also returns the sum of squared divergences of the carrying velocity (what residual() adds up),
+// evaluated by the advection kernel itself; the call then waits for that number.
 template <typename T>
-int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false, bool reflect = false) {
+int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool copy_to_tmp = false, bool reflect = false,
+           double* res_sum = nullptr) {
     FS_TRY(prepare(s, HALO_ALL | (q_from_tmp ? HALO_TMP : 0)));
     const bool slab = s->nparts_global > 1;
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
@@ -868,17 +911,29 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
         const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
         const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
         const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
-        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
-        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
-        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
-        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect)));
+        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
+        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
+        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
+        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
     }
     SIM_HIP(hipGetLastError());
+    if (res_sum) {   // queued before the halo exchange, so that the host need not wait for that
+        for (int k = 0; k < s->nlocal; ++k)
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, s->parts[k].adv_part, s->parts[k].adv_blocks,
+                               s->dres + 2 * k);
+        SIM_HIP(hipGetLastError());
+        FS_TRY(queue_reduction(s, false));
+    }
     s->curv = ov;
     s->curd = od;
     s->halo_dirty |= HALO_ALL | (copy_to_tmp ? HALO_TMP : 0);
     // start the exchange of the new planes now; whoever needs them waits (join_halos)
     FS_TRY(refresh_halos(s, HALO_ALL | HALO_TMP, true));
+    if (res_sum) {
+        SIM_HIP(hipStreamSynchronize(s->stream));
+        *res_sum = s->hres[0];
+        return oob_status(s);
+    }
     return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }
 
@@ -928,6 +983,61 @@ int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
     return refresh_halos(s, HALO_ALL | HALO_TMP, true);
 }
 
+// Sweeps the deferred check runs unverified, or 0 if this projection evaluates its stopping rule itself.
+// Deferred check (check_every = FS_CHECK_DEFERRED): where the same projection of the previous step needed at most
+// three sweeps, that many are run without evaluating the residual; the advection that follows reads the
+// projected field anyway and adds up its squared divergences on the way (fs_advect_tiled.hpp).  If the residual
+// meets the tolerance (nearly always: consecutive steps need the same count) the step has saved the residual
+// passes; if not, the advected generation is dropped (the projected field is still intact in the other one),
+// the projection goes on with a check after every sweep and the advection is repeated.  Every projection
+// still ends on a verified residual <= tol.  A failure is paid for by 2, 4, 8 projections without deferral;
+// after 8 deferred projections at more than one sweep, one evaluates the rule itself (the count may have dropped).
+int deferred_sweeps(fs3d_sim* s, int slot, bool mac) {
+    const fs3d_config& c = s->cfg;
+    if (c.check_every != FS_CHECK_DEFERRED || c.stop_mode != FS_STOP_L2_RESIDUAL || c.solver != FS_SOLVER_SWEEPS ||
+        c.ordering != FS_ORDER_RED_BLACK || c.advect_kernel != FS_ADVECT_TILED || mac)
+        return 0;
+    const int h = s->sweep_hint[slot];
+    if (h > 3 || h > c.max_iters) return 0;
+    if (s->spec_backoff[slot] > 0) { --s->spec_backoff[slot]; return 0; }
+    if (h > 1 && s->spec_streak[slot] >= 8) { s->spec_streak[slot] = 0; return 0; }
+    return h;
+}
+
+// A projection followed by the advection `adv(res_sum)` that reads the projected field.
+template <typename T, typename Adv>
+int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projection, Adv adv) {
+    const int n = deferred_sweeps(s, slot, mac);
+    if (n == 0) {
+        FS_TRY(project<T>(s, nullptr, nullptr, slot));
+        if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
+        return adv(nullptr);
+    }
+    FS_TRY(project<T>(s, nullptr, nullptr, slot, n));
+    if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
+    double sum = 0;
+    FS_TRY(adv(&sum));
+    const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
+    const double metric = sqrt(sum) / ninterior / s->resid_dt;   // as residual() and project() form it
+    if (!(metric > s->cfg.tol)) {
+        s->stats.metric = metric;
+        s->sweep_hint[slot] = n;
+        s->spec_fails[slot] = 0;
+        s->spec_streak[slot] = n > 1 ? s->spec_streak[slot] + 1 : 0;
+        return FS_OK;
+    }
+    // not converged after all: back to the projected field, which the advection only read
+    FS_TRY(join_halos(s));
+    s->curv ^= 1;
+    s->curd ^= 1;
+    s->halo_dirty |= HALO_ALL;
+    s->spec_fails[slot] = std::min(s->spec_fails[slot] + 1, 3);
+    s->spec_backoff[slot] = 1 << s->spec_fails[slot];
+    s->spec_streak[slot] = 0;
+    FS_TRY(project<T>(s, nullptr, nullptr, slot, 0, n));
+    return adv(nullptr);
+}
+
 template <typename T>
 int step(fs3d_sim* s, double dt) {
     s->stats.sweeps_step = 0;
@@ -937,25 +1047,27 @@ int step(fs3d_sim* s, double dt) {
     const bool mac = s->cfg.advection == FS_ADVECTION_MACCORMACK;
     if (s->cfg.step_mode == FS_STEP_REFERENCE) {
         // FluidSim::update (main.cpp:102-130)
-        FS_TRY(project<T>(s, nullptr, nullptr));
-        SIM_HIP(hipEventRecord(s->ev[1], s->stream));
-        FS_TRY(advect<T>(s, dt, false, mac ? 0 : 1));
-        if (mac) FS_TRY(maccormack<T>(s, dt, false, false));
+        FS_TRY((project_then_advect<T>(s, 0, mac, s->ev[1], [&](double* res) -> int {
+            FS_TRY(advect<T>(s, dt, false, mac ? 0 : 1, false, false, res));
+            if (mac) FS_TRY(maccormack<T>(s, dt, false, false));
+            return (int)FS_OK;
+        })));
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     } else {
         // Advection-reflection, phase-shifted to the reference's convention of projecting first and
         // leaving the advected field for the next step to project:
         //   u0 = P(state); ut = A(u0; u0, dt/2); uh = P(ut); ur = 2 uh - ut; state = A(ur; uh, dt/2)
-        FS_TRY(project<T>(s, nullptr, nullptr));
-        FS_TRY(advect<T>(s, 0.5 * dt, false, 0, !mac));   // ut goes to the scratch fields as well
-        if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, false, true));
-        FS_TRY(project<T>(s, nullptr, nullptr, 1));
-        SIM_HIP(hipEventRecord(s->ev[1], s->stream));
-        if (s->cfg.advect_kernel == FS_ADVECT_TILED && !mac) {
-            // the staged kernel forms ur while it loads ut and uh: no reflection pass
-            FS_TRY(advect<T>(s, 0.5 * dt, true, 0, false, true));
-        } else {
+        FS_TRY((project_then_advect<T>(s, 0, mac, nullptr, [&](double* res) -> int {
+            FS_TRY(advect<T>(s, 0.5 * dt, false, 0, !mac, false, res));   // ut goes to the scratch fields as well
+            if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, false, true));
+            return (int)FS_OK;
+        })));
+        FS_TRY((project_then_advect<T>(s, 1, mac, s->ev[1], [&](double* res) -> int {
+            if (s->cfg.advect_kernel == FS_ADVECT_TILED && !mac) {
+                // the staged kernel forms ur while it loads ut and uh: no reflection pass
+                return advect<T>(s, 0.5 * dt, true, 0, false, true, res);
+            }
             FS_TRY(prepare(s, HALO_VEL | HALO_TMP));   // the reflection runs over halo planes too
             for (Part& p : s->parts)
                 hipLaunchKernelGGL(k_reflect<T>, dim3(2048), dim3(256), 0, s->stream, (int64_t)p.n, F<T>(p, s->curv, 0),
@@ -964,7 +1076,8 @@ int step(fs3d_sim* s, double dt) {
             SIM_HIP(hipGetLastError());
             FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
             if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, true, false));
-        }
+            return (int)FS_OK;
+        })));
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     }
@@ -1175,7 +1288,7 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->stop_mode < FS_STOP_FIXED || c->stop_mode > FS_STOP_L2_RESIDUAL) { *why = "bad stop_mode"; return false; }
     if (c->step_mode != FS_STEP_REFERENCE && c->step_mode != FS_STEP_REFLECTION) { *why = "bad step_mode"; return false; }
     if (c->max_iters < 1) { *why = "max_iters must be >= 1"; return false; }
-    if (c->check_every < 0) { *why = "check_every must be >= 0"; return false; }
+    if (c->check_every < FS_CHECK_DEFERRED) { *why = "check_every must be >= 1, FS_CHECK_ADAPTIVE or FS_CHECK_DEFERRED"; return false; }
     if (c->local_slabs < 1) { *why = "local_slabs must be >= 1"; return false; }
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (c->advect_kernel < FS_ADVECT_TILED || c->advect_kernel > FS_ADVECT_DIRECT) { *why = "bad advect_kernel"; return false; }

@@ -33,13 +33,17 @@ struct AdvTile {
 // SEP: the carrying velocity (U,V,W) is not (qu,qv,qw).  SLAB: the arrays hold only some planes of the grid.
 // REFL (needs SEP): the carried velocity is the reflection 2*(U,V,W) - (qu,qv,qw) of the given field about
 // the carrying one (Zehnder et al. 2018, Alg. 1), formed while staging instead of by a pass of its own.
+// res_part (optional): the carrying velocity is the field a projection has just left, and its six faces per
+// cell are in registers here anyway; the kernel then also adds up the squared divergences that k_div_sumsq
+// would (same cells, same per-cell value), one partial sum per workgroup, so that the projection's stopping
+// rule can be verified without a pass of its own over the velocity.
 template <typename T, typename OFF, bool SEP, bool SLAB, bool REFL = false>
 __global__ void __launch_bounds__(512)
 k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
                const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
                T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od, T* __restrict__ cu,
                T* __restrict__ cv, T* __restrict__ cw, const uint8_t* __restrict__ flags, T t_step, int density_mode,
-               int zb, int ze, int zchunk, int* __restrict__ oob_flag) {
+               int zb, int ze, int zchunk, int* __restrict__ oob_flag, double* __restrict__ res_part) {
     using C = AdvTile<T, SEP>;
     constexpr int R = C::R, WX = C::WX, PS = C::PS, NPL = C::NPL;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -132,6 +136,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         return fast_finish(tr, t);
     };
 
+    double racc = 0;
     auto compute = [&](int z, uint32_t fl) {
         const int gz = z + g.gz0;
         const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
@@ -147,6 +152,13 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uc[-WX], u_xp_ym = Uc[1 - WX], u_zm = Uzm[0], u_xp_zm = Uzm[1];
             const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vc[WX], v_xm_yp = Vc[WX - 1], v_zm = Vzm[0], v_yp_zm = Vzm[WX];
             const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wc[-WX], w_ym_zp = Wzp[-WX];
+            if (res_part) {   // the cells and the value of k_div_sumsq
+                const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
+                if (relaxes(fl) && movable) {
+                    const double dv = (double)((u_xp - u_c) + (v_yp - v_c) + (w_zp - w_c));
+                    racc += dv * dv;
+                }
+            }
             // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
             const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
             const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
@@ -188,6 +200,20 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         if (mine) compute(z, fl);
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
         __syncthreads();
+    }
+    if (res_part) {   // one partial per workgroup, added in a fixed order
+        double* red = reinterpret_cast<double*>(lds_raw);
+        racc = wave_sum(racc);
+        if ((tid & 63) == 0) red[tid >> 6] = racc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < C::NT / 64; ++k) t += red[k];
+            const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            res_part[2 * bid] = t;
+            res_part[2 * bid + 1] = 0;
+        }
     }
 }
 

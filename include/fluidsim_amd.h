@@ -67,6 +67,22 @@ enum {
                                 to fs3d_advance / fs3d_update, and 1 for a bare fs3d_project          */
 };
 
+/* special values of fs3d_config.check_every */
+enum {
+    FS_CHECK_ADAPTIVE = 0,   /* first evaluation one sweep before the count the same projection of the
+                                previous step needed, then after every sweep                        */
+    FS_CHECK_DEFERRED = -1   /* as FS_CHECK_ADAPTIVE, but inside fs3d_advance a projection whose previous
+                                count was at most 3 runs that many sweeps unverified and the advection
+                                that follows (which reads the projected field anyway) evaluates the L2
+                                residual on the way; if it exceeds tol the advected field is dropped,
+                                the projection goes on with a check per sweep and the advection is
+                                repeated.  Every projection still ends on a verified residual <= tol;
+                                the count can exceed that of check_every = 1 by one sweep for a few steps
+                                while it is falling.  Needs FS_STOP_L2_RESIDUAL, red-black order, the
+                                sweeps solver, FS_ADVECT_TILED and semi-Lagrange; otherwise it acts as
+                                FS_CHECK_ADAPTIVE                                                   */
+};
+
 /* implementation of one red-black sweep (same result bit for bit) */
 enum {
     FS_SWEEP_FUSED = 0,      /* both colours in one pass over HBM, out of place: the register-resident
@@ -114,8 +130,8 @@ typedef struct fs3d_config {
     int32_t ordering;     /* FS_ORDER_*                                                           */
     int32_t stop_mode;    /* FS_STOP_*                                                            */
     int32_t max_iters;    /* sweep cap; the reference uses 1000 (main.cpp:108)                    */
-    int32_t check_every;  /* evaluate the stopping metric every n-th sweep; 0 = adaptive: first one
-                             sweep before the count the previous step needed, then every sweep      */
+    int32_t check_every;  /* evaluate the stopping metric every n-th sweep; or FS_CHECK_ADAPTIVE (0),
+                             FS_CHECK_DEFERRED (-1)                                                  */
     int32_t step_mode;    /* FS_STEP_*                                                            */
     int32_t local_slabs;  /* >= 1: cut this handle's planes into that many z-slabs on its own GPU
                              (exercises the multi-GPU slab path inside one process)            */

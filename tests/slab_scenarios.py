@@ -73,14 +73,14 @@ def steps_maccormack(fs, **kw):
     return rec
 
 
-def vortex_ring(fs, **kw):
+def vortex_ring(fs, check_every=0, steps=3, **kw):
     """The benchmark scene (emitter in global coordinates, density re-stamp) at a small size."""
     n = 48
-    g = fs.FluidSim3D(n, n, n, device=0, stop_mode=fs.STOP_L2_RESIDUAL, tol=1e-4, max_iters=40, check_every=0,
+    g = fs.FluidSim3D(n, n, n, device=0, stop_mode=fs.STOP_L2_RESIDUAL, tol=1e-4, max_iters=40, check_every=check_every,
                       step_mode=1, **kw)
     g.sphere_influence(n / 10.0)
     rec = {}
-    for it in range(3):
+    for it in range(steps):
         g.fill_sphere_influence(n / 10.0, it)
         g.advance(1.0 / 30.0)
         _snapshot(g, rec, f"s{it}")
@@ -88,7 +88,13 @@ def vortex_ring(fs, **kw):
     return rec
 
 
-SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, steps_maccormack, vortex_ring)}
+def vortex_ring_deferred(fs, **kw):
+    """The same with the residual evaluated by the advection that follows each projection."""
+    return vortex_ring(fs, check_every=-1, steps=8, **kw)
+
+
+SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, steps_maccormack, vortex_ring,
+                                     vortex_ring_deferred)}
 
 
 def run(fs, name, rank=0, nranks=1, comm_id=None):

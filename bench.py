@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--local-slabs", type=int, default=1,
                     help="cut each rank's planes into this many z-slabs on its own GPU (rehearses the slab path)")
     ap.add_argument("--no-multigrid-leg", action="store_true", help="skip the extra run with the multigrid solver")
+    ap.add_argument("--no-512-leg", action="store_true", help="skip the extra single-GPU run of the 512^3 configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--max-iters", type=int, default=1000)
@@ -94,12 +95,11 @@ def cpu_baseline(n, sweeps_per_step, sample_sweeps=None):
     }
 
 
-def multigrid_leg(fs, scenes, a, nx, ny, nz, device):
-    """The same steps on a fresh state with FS_SOLVER_MULTIGRID (V-cycles around the same red-black sweeps, same
-    stopping rule): reported beside the headline value, which stays on the sweeps-only solver."""
+def extra_leg(fs, scenes, a, nx, ny, nz, device, solver, note):
+    """The same steps on a fresh single-GPU state with another solver or grid, reported beside the headline value."""
     sim = fs.FluidSim3D(nx, ny, nz, device=device, dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters, check_every=a.check_every,
-                        omega=a.omega, step_mode=a.step_mode, solver=1, buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
+                        omega=a.omega, step_mode=a.step_mode, solver=solver, buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
     scene_init, scene_step = scenes.SCENES[a.scene]
     scene_init(sim)
     it = 0
@@ -117,9 +117,14 @@ def multigrid_leg(fs, scenes, a, nx, ny, nz, device):
     elapsed = time.perf_counter() - t0
     st = sim.stats()
     sim.close()
-    return {"value": nx * ny * nz / (elapsed / a.steps) / 1e6, "unit": "Mcells/s", "ms_per_step": elapsed / a.steps * 1e3,
-            "sweeps_per_step": sweeps / a.steps, "last_residual": st.metric,
-            "note": "V(2,2) cycles, 2x2x2 coarsening, piecewise-constant transfer, a cycle counted as 4 sweeps"}
+    return {"grid": [nx, ny, nz], "value": nx * ny * nz / (elapsed / a.steps) / 1e6, "unit": "Mcells/s",
+            "ms_per_step": elapsed / a.steps * 1e3, "sweeps_per_step": sweeps / a.steps, "last_residual": st.metric, "note": note}
+
+
+def multigrid_leg(fs, scenes, a, nx, ny, nz, device):
+    return extra_leg(fs, scenes, a, nx, ny, nz, device, 1,
+                     "FS_SOLVER_MULTIGRID: V(2,2) cycles around the same red-black sweeps, 2x2x2 coarsening, "
+                     "piecewise-constant transfer, same stopping rule, a cycle counted as 4 sweeps")
 
 
 def main():
@@ -236,6 +241,11 @@ def main():
                 "blocking_factor": 2,
                 "hbm_model_bytes_per_launch": 0.5 * sweep_bytes * cells_local,
                 "hbm_model_rate": 0.5 * sweep_bytes * cells_local / launch_s / 1e9,
+                # the whole step against the same peak: advection 25 + reflection 36 + advection 45 + 50 per sweep
+                # algorithmic bytes per cell (fp32), over the measured step time
+                "full_step_bytes_per_cell": 25 + 36 + 45 + 50 * sweeps_per_step,
+                "full_step_frac": (25 + 36 + 45 + 50 * sweeps_per_step) * esz_scale * cells / (elapsed / a.steps) / 1e9
+                                  / HBM_PEAK_GBS / world,
             },
         }
         pmc = os.path.join(ROOT, "profiles", "sweep_traffic.json")
@@ -248,6 +258,16 @@ def main():
                 pass
         if world == 1 and a.solver == "sweeps" and a.local_slabs == 1 and not a.no_multigrid_leg:
             line["solver_multigrid"] = multigrid_leg(fs, scenes, a, nx, ny, nz, device)
+        big = (512, 512, 512)
+        if not a.no_512_leg and a.scene == "vortex_ring" and not a.n and not a.grid and a.dtype == "f32" and a.solver == "sweeps":
+            # the configuration the multi-GPU lines are quoted on, on this rank's GPU alone (the other ranks wait):
+            # with N = 1 it sits beside the 256^3 headline, with N > 1 it is the base of the strong-scaling ratio
+            leg = extra_leg(fs, scenes, a, *big, device, 0, "vortex ring 512^3 on one GPU, same steps and stopping rule")
+            leg["hbm_roofline_frac_full_step"] = ((25 + 36 + 45 + 50 * leg["sweeps_per_step"]) * big[0] * big[1] * big[2]
+                                                  / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            line["one_gpu_512"] = leg
+            if world > 1 and (nx, ny, nz) == big:
+                line["speedup_vs_one_gpu"] = line["value"] / leg["value"]
         if world == 1 and not a.no_cpu_baseline and a.scene == "vortex_ring" and not a.grid and a.dtype == "f32":
             line["cpu_baseline"] = cpu_baseline(n, sweeps_per_step)
         print(json.dumps(line), flush=True)

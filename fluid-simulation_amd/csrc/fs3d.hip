@@ -773,7 +773,17 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
     const int first = resume_from > 0 ? resume_from + 1 : adaptive ? std::max(1, s->sweep_hint[slot & 1] - 1) : 1;
     // two early evaluations, at a quarter and at half of the expected count: a count that collapses (the step
     // after a start-up transient) is then found within a step or two, and a stale hint cannot cost much
+    // past the expected count the evaluations thin out (every sweep for eight sweeps, then one sweep in nine
+    // of the excess): a projection that runs far beyond its hint, such as the first of a run, is not charged
+    // an evaluation per sweep, and overshoots its stopping sweep by at most an eighth of that excess
     const int early1 = first / 4, early2 = first / 2;
+    auto check_after = [&](int done) {   // the sweep count of the next evaluation once `done` sweeps are behind
+        if (done < early1) return early1;
+        if (done < early2) return early2;
+        if (done < first) return first;
+        return done + 1 + (done - first) / 8;
+    };
+    int next_check = check_after(resume_from);
     int it = resume_from;
     double metric = 0;
     if (unchecked > 0) {
@@ -819,14 +829,14 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
         }
     } else
     for (;;) {
-        const bool check = (adaptive ? (it + 1 >= first || it + 1 == early1 || it + 1 == early2) : ((it + 1) % every == 0)) ||
-                           (it + 1 >= c.max_iters);
+        const bool check = (adaptive ? it + 1 == next_check : ((it + 1) % every == 0)) || (it + 1 >= c.max_iters);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
             FS_TRY(sweep_with_change<T>(s, &metric));
         } else {
             FS_TRY(sweep_once<T>(s));
         }
         ++it;
+        if (check) next_check = check_after(it);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check && !(metric > c.tol)) break;
         if (c.stop_mode == FS_STOP_L2_RESIDUAL && check) {
             FS_TRY(residual<T>(s, &metric, nullptr, false));

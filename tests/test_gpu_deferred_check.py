@@ -29,7 +29,7 @@ def run_pair(fsamd, a, b, steps, dt, n=None, disturb_at=()):
                 g.fill_sphere_influence(n / 10.0, it)
             if it in disturb_at:   # a kick the previous step's count cannot have foreseen
                 w = g.get_field(2)
-                w[w.shape[0] // 3: w.shape[0] // 2, 5:12, 5:12] += 40.0
+                w[w.shape[0] // 3: w.shape[0] // 2, 5:12, 5:12] += 3.0
                 g.set_field(2, w)
             g.advance(dt)
         sa, sb = a.stats(), b.stats()

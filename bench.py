@@ -179,11 +179,13 @@ def main():
         sim.advance(DT)
     barrier()
     t0 = time.perf_counter()
-    sweeps = 0
+    sweeps = evals = 0
     for _ in range(a.steps):
         scene_step(sim, it); it += 1
         sim.advance(DT)
-        sweeps += sim.stats().sweeps_step
+        st_ = sim.stats()
+        sweeps += st_.sweeps_step
+        evals += st_.evaluations_step
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -229,7 +231,8 @@ def main():
                                "kernel that reads its result (redone with more sweeps if the residual exceeds the tolerance)"
                                if a.check_every == -1 else f"checked every {a.check_every}"),
                 "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}" + (f" (x{a.local_slabs} slabs per GPU)" if a.local_slabs > 1 else ""),
-                "sweeps_per_step": sweeps_per_step, "last_residual": st.metric,
+                "sweeps_per_step": sweeps_per_step, "residual_passes_per_step": evals / a.steps,
+                "redone_advections": st.redone, "last_residual": st.metric,
                 "residual_norm": "sqrt(sum (div/dt)^2) / #interior cells, the norm of 3_fluid/FluidSim.cpp:25-43",
                 "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
             },

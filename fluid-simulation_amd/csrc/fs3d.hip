@@ -77,8 +77,7 @@ struct fs3d_sim {
     int mg_backoff[2] = {0, 0};  // projections to wait before plain sweeps are tried again under the multigrid solver
     int mg_fails[2] = {0, 0};    // consecutive failed tries
     int spec_backoff[2] = {0, 0};   // deferred residual check: projections to wait after a failed one,
-    int spec_fails[2] = {0, 0};     // consecutive failures,
-    int spec_streak[2] = {0, 0};    // consecutive successes with more than one sweep
+    int spec_fails[2] = {0, 0};     // consecutive failures
     bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
@@ -98,6 +97,7 @@ struct fs3d_sim {
     fs3d_stats stats{};
     int num_cus = 256;
     int sweep_hint[2] = {1, 1};  // sweeps the first / second projection of the previous step needed
+    int sweep_hint_prev[2] = {0, 0};   // and of the step before that
     double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
     std::string err;
 };
@@ -608,6 +608,7 @@ int snapshot_velocity(fs3d_sim* s) {   // main.cpp:192-196; the other generation
 
 template <typename T>
 int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
+    ++s->stats.evaluations_step;
     FS_TRY(join_halos(s));   // the planes next to a slab interface were swept on the second stream
     if (s->cfg.ordering == FS_ORDER_LEXICOGRAPHIC) {
         Part& p = s->parts[0];
@@ -633,6 +634,7 @@ int change_since_snapshot(fs3d_sim* s, double* change) {   // main.cpp:243-249
 
 template <typename T>
 int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
+    ++s->stats.evaluations_step;
     FS_TRY(join_halos(s));   // the top owned plane reads w of the first halo plane
     for (int k = 0; k < s->nlocal; ++k) {
         Part& p = s->parts[k];
@@ -761,22 +763,28 @@ int sweep_with_change(fs3d_sim* s, double* change) {
 // same number of sweeps, so this costs one or two evaluations and stops at the exact sweep), and twice on
 // the way there.
 // unchecked > 0: exactly that many sweeps and no evaluation (the caller verifies the stopping rule afterwards);
-// resume_from > 0: the projection already holds that many sweeps and goes on, evaluating after every sweep.
+// resume_from > 0: the projection already holds that many sweeps and goes on, evaluating after every sweep;
+// deferred != nullptr: if the evaluation one sweep before the expected count fails, the expected last sweep
+// runs unverified and *deferred is set: the caller verifies the stopping rule (and resumes if it is not met).
 template <typename T>
-int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int unchecked = 0, int resume_from = 0) {
+int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int unchecked = 0, int resume_from = 0,
+            bool* deferred = nullptr) {
     // the interior of a one-pass sweep reads no halo plane: let the exchange run beside it
     const bool one_pass = s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
     FS_TRY(prepare(s, HALO_VEL, one_pass));
     const fs3d_config& c = s->cfg;
     const bool adaptive = c.check_every <= 0;
     const int every = std::max(1, c.check_every);
-    const int first = resume_from > 0 ? resume_from + 1 : adaptive ? std::max(1, s->sweep_hint[slot & 1] - 1) : 1;
+    const int hint = s->sweep_hint[slot & 1];
+    const int first = resume_from > 0 ? resume_from + 1 : adaptive ? std::max(1, hint - 1) : 1;
     // two early evaluations, at a quarter and at half of the expected count: a count that collapses (the step
     // after a start-up transient) is then found within a step or two, and a stale hint cannot cost much
     // past the expected count the evaluations thin out (every sweep for eight sweeps, then one sweep in nine
     // of the excess): a projection that runs far beyond its hint, such as the first of a run, is not charged
     // an evaluation per sweep, and overshoots its stopping sweep by at most an eighth of that excess
-    const int early1 = first / 4, early2 = first / 2;
+    // (not while the count is steady: within an eighth of the one before)
+    const bool steady = std::abs(hint - s->sweep_hint_prev[slot & 1]) <= std::max(1, hint / 8);
+    const int early1 = steady ? 0 : first / 4, early2 = steady ? 0 : first / 2;
     auto check_after = [&](int done) {   // the sweep count of the next evaluation once `done` sweeps are behind
         if (done < early1) return early1;
         if (done < early2) return early2;
@@ -800,7 +808,6 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
         // two plain sweeps are tried first.
         bool done = false;
         int& backoff = s->mg_backoff[slot & 1];
-        const int hint = s->sweep_hint[slot & 1];
         const bool try_plain = c.stop_mode == FS_STOP_L2_RESIDUAL && c.max_iters > 2 &&
                                (hint <= 2 || (hint <= kMgNu1 + kMgNu2 + 2 && backoff == 0));
         if (backoff > 0) --backoff;
@@ -829,6 +836,13 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
         }
     } else
     for (;;) {
+        if (deferred && it == first && it + 1 == hint && it + 1 < c.max_iters) {
+            // the evaluation at `first` has just failed: the sweep the hint expects to be the last
+            FS_TRY(sweep_once<T>(s));
+            ++it;
+            *deferred = true;
+            break;
+        }
         const bool check = (adaptive ? it + 1 == next_check : ((it + 1) % every == 0)) || (it + 1 >= c.max_iters);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
             FS_TRY(sweep_with_change<T>(s, &metric));
@@ -846,7 +860,9 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
         if (it >= c.max_iters) break;
     }
     // a projection that ran into the cap says nothing about the next one: start checking at once
-    s->sweep_hint[slot & 1] = (it >= c.max_iters && metric > c.tol) ? 1 : it;
+    const bool capped = it >= c.max_iters && metric > c.tol;
+    s->sweep_hint_prev[slot & 1] = (resume_from > 0 || capped) ? 0 : hint;   // (mispredicted or capped: not steady)
+    s->sweep_hint[slot & 1] = capped ? 1 : it;
     s->stats.sweeps = it;
     s->stats.sweeps_step += it - resume_from;
     s->stats.metric = metric;
@@ -993,47 +1009,52 @@ int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
     return refresh_halos(s, HALO_ALL | HALO_TMP, true);
 }
 
-// Sweeps the deferred check runs unverified, or 0 if this projection evaluates its stopping rule itself.
-// Deferred check (check_every = FS_CHECK_DEFERRED): where the same projection of the previous step needed at most
-// three sweeps, that many are run without evaluating the residual; the advection that follows reads the
-// projected field anyway and adds up its squared divergences on the way (fs_advect_tiled.hpp).  If the residual
-// meets the tolerance (nearly always: consecutive steps need the same count) the step has saved the residual
-// passes; if not, the advected generation is dropped (the projected field is still intact in the other one),
-// the projection goes on with a check after every sweep and the advection is repeated.  Every projection
-// still ends on a verified residual <= tol.  A failure is paid for by 2, 4, 8 projections without deferral;
-// after 8 deferred projections at more than one sweep, one evaluates the rule itself (the count may have dropped).
-int deferred_sweeps(fs3d_sim* s, int slot, bool mac) {
+// Deferred check (check_every = FS_CHECK_DEFERRED).  The advection that follows a projection reads the projected
+// field anyway and can add up its squared divergences on the way (fs_advect_tiled.hpp), so the last evaluation
+// of a projection need not be a pass of its own:
+//  - where the same projection of the previous step needed one sweep, that sweep runs unverified;
+//  - else the residual is evaluated one sweep before the expected count (the count may have dropped) and, if
+//    that fails, the expected last sweep runs unverified.
+// If the advection then reports a residual <= tol (nearly always: consecutive steps need the same count) the
+// step has saved residual passes; if not, the advected generation is dropped (the projected field is still
+// intact in the other one), the projection goes on with evaluations of its own and the advection is repeated.
+// Every projection still ends on a verified residual <= tol.  A miss is paid for by 2, 4, 8 projections
+// without deferral.
+// Returns -1: no deferral; 0: deferral of the last evaluation only; 1: one sweep, unverified.
+int deferral(fs3d_sim* s, int slot, bool mac) {
     const fs3d_config& c = s->cfg;
     if (c.check_every != FS_CHECK_DEFERRED || c.stop_mode != FS_STOP_L2_RESIDUAL || c.solver != FS_SOLVER_SWEEPS ||
         c.ordering != FS_ORDER_RED_BLACK || c.advect_kernel != FS_ADVECT_TILED || mac)
-        return 0;
+        return -1;
+    if (s->spec_backoff[slot] > 0) { --s->spec_backoff[slot]; return -1; }
     const int h = s->sweep_hint[slot];
-    if (h > 3 || h > c.max_iters) return 0;
-    if (s->spec_backoff[slot] > 0) { --s->spec_backoff[slot]; return 0; }
-    if (h > 1 && s->spec_streak[slot] >= 8) { s->spec_streak[slot] = 0; return 0; }
-    return h;
+    // a miss costs an advection, several evaluations' worth: only where the last two steps agreed on the count
+    // and where an evaluation is a good part of the projection's cost (at twenty sweeps the count wanders by one
+    // from step to step, and one evaluation in three is not worth the risk)
+    if (h >= c.max_iters || h != s->sweep_hint_prev[slot] || h > 4) return -1;
+    return h > 1 ? 0 : 1;
 }
 
 // A projection followed by the advection `adv(res_sum)` that reads the projected field.
 template <typename T, typename Adv>
 int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projection, Adv adv) {
-    const int n = deferred_sweeps(s, slot, mac);
-    if (n == 0) {
-        FS_TRY(project<T>(s, nullptr, nullptr, slot));
-        if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
-        return adv(nullptr);
-    }
-    FS_TRY(project<T>(s, nullptr, nullptr, slot, n));
+    const int mode = deferral(s, slot, mac);
+    bool deferred = mode > 0;
+    FS_TRY(project<T>(s, nullptr, nullptr, slot, std::max(mode, 0), 0, mode == 0 ? &deferred : nullptr));
     if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
+    if (!deferred) return adv(nullptr);
+    const int n = s->stats.sweeps;
     double sum = 0;
     FS_TRY(adv(&sum));
     const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
     const double metric = sqrt(sum) / ninterior / s->resid_dt;   // as residual() and project() form it
     if (!(metric > s->cfg.tol)) {
         s->stats.metric = metric;
-        s->sweep_hint[slot] = n;
+        if (mode > 0) {
+            s->sweep_hint_prev[slot] = s->sweep_hint[slot];
+            s->sweep_hint[slot] = n;
+        }
         s->spec_fails[slot] = 0;
-        s->spec_streak[slot] = n > 1 ? s->spec_streak[slot] + 1 : 0;
         return FS_OK;
     }
     // not converged after all: back to the projected field, which the advection only read
@@ -1043,7 +1064,7 @@ int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projec
     s->halo_dirty |= HALO_ALL;
     s->spec_fails[slot] = std::min(s->spec_fails[slot] + 1, 3);
     s->spec_backoff[slot] = 1 << s->spec_fails[slot];
-    s->spec_streak[slot] = 0;
+    ++s->stats.redone;
     FS_TRY(project<T>(s, nullptr, nullptr, slot, 0, n));
     return adv(nullptr);
 }
@@ -1051,6 +1072,7 @@ int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projec
 template <typename T>
 int step(fs3d_sim* s, double dt) {
     s->stats.sweeps_step = 0;
+    s->stats.evaluations_step = 0;
     s->resid_dt = dt > 0 ? dt : 1.0;
     SIM_HIP(hipEventRecord(s->ev[0], s->stream));
     if (s->cfg.buoyancy != 0.0) FS_TRY(buoyancy<T>(s, dt));
@@ -1497,6 +1519,8 @@ int fs3d_reset(fs3d_sim* s) {
     s->curv = 0;
     s->curd = 0;
     s->sweep_hint[0] = s->sweep_hint[1] = 1;
+    s->sweep_hint_prev[0] = s->sweep_hint_prev[1] = 0;
+    for (int k = 0; k < 2; ++k) s->spec_backoff[k] = s->spec_fails[k] = s->mg_backoff[k] = s->mg_fails[k] = 0;
     s->mg_backoff[0] = s->mg_backoff[1] = 0;
     s->mg_fails[0] = s->mg_fails[1] = 0;
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
@@ -1769,12 +1793,34 @@ int fs3d_get_density_downsampled(fs3d_sim* s, int factor, void* host, size_t cou
 // Restart file: a 64-byte header, then the cell types (1 byte per cell) and u, v, w, density of the whole
 // grid, x fastest.  Every rank writes (reads) its owned planes at their place in the one file.
 namespace {
+// The schedule of residual evaluations depends on a few small counters; a continued run repeats the
+// uninterrupted one only if they come along.
+uint32_t pack_schedule(const fs3d_sim* s) {
+    uint32_t v = 0;
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t f = (uint32_t)(s->spec_backoff[k] & 15) | (uint32_t)(s->spec_fails[k] & 3) << 4 |
+                           (uint32_t)(s->mg_backoff[k] & 15) << 10 |
+                           (uint32_t)(s->mg_fails[k] & 3) << 14;
+        v |= f << (16 * k);
+    }
+    return v;
+}
+void unpack_schedule(fs3d_sim* s, uint32_t v) {
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t f = v >> (16 * k);
+        s->spec_backoff[k] = f & 15; s->spec_fails[k] = (f >> 4) & 3;
+        s->mg_backoff[k] = (f >> 10) & 15; s->mg_fails[k] = (f >> 14) & 3;
+    }
+}
+
 struct RestartHeader {
     char magic[8];            // "FSAMD3D"
-    int32_t version, dtype, nx, ny, nz, hint0, hint1, pad;
+    int32_t version, dtype, nx, ny, nz, hint0, hint1, prev0;
     int64_t step;
     double time;
-    int64_t reserved;
+    int32_t prev1;
+    uint32_t sched;           // the counters of the evaluation schedule, see pack_schedule
+
 };
 static_assert(sizeof(RestartHeader) == 64, "restart header is 64 bytes");
 
@@ -1803,6 +1849,8 @@ int fs3d_save(fs3d_sim* s, const char* path) {
         memcpy(h.magic, "FSAMD3D", 8);
         h.version = 1; h.dtype = s->cfg.dtype; h.nx = s->nx; h.ny = s->ny; h.nz = s->nz;
         h.hint0 = s->sweep_hint[0]; h.hint1 = s->sweep_hint[1];
+        h.prev0 = s->sweep_hint_prev[0]; h.prev1 = s->sweep_hint_prev[1];
+        h.sched = pack_schedule(s);
         h.step = s->stats.step; h.time = s->stats.time;
         rc = file_io(s, fd, true, &h, sizeof(h), 0);
     }
@@ -1844,6 +1892,8 @@ int fs3d_load(fs3d_sim* s, const char* path) {
     (void)close(fd);
     if (rc != FS_OK) return rc;
     s->sweep_hint[0] = std::max(1, h.hint0); s->sweep_hint[1] = std::max(1, h.hint1);
+    s->sweep_hint_prev[0] = h.prev0; s->sweep_hint_prev[1] = h.prev1;
+    unpack_schedule(s, h.sched);
     s->stats = fs3d_stats{};
     s->stats.step = h.step; s->stats.time = h.time;
     return FS_OK;

@@ -71,16 +71,17 @@ enum {
 enum {
     FS_CHECK_ADAPTIVE = 0,   /* first evaluation one sweep before the count the same projection of the
                                 previous step needed, then after every sweep                        */
-    FS_CHECK_DEFERRED = -1   /* as FS_CHECK_ADAPTIVE, but inside fs3d_advance a projection whose previous
-                                count was at most 3 runs that many sweeps unverified and the advection
-                                that follows (which reads the projected field anyway) evaluates the L2
-                                residual on the way; if it exceeds tol the advected field is dropped,
-                                the projection goes on with a check per sweep and the advection is
-                                repeated.  Every projection still ends on a verified residual <= tol;
-                                the count can exceed that of check_every = 1 by one sweep for a few steps
-                                while it is falling.  Needs FS_STOP_L2_RESIDUAL, red-black order, the
-                                sweeps solver, FS_ADVECT_TILED and semi-Lagrange; otherwise it acts as
-                                FS_CHECK_ADAPTIVE                                                   */
+    FS_CHECK_DEFERRED = -1   /* as FS_CHECK_ADAPTIVE, but inside fs3d_advance the last evaluation of a
+                                projection is left to the advection that follows (which reads the
+                                projected field anyway and adds up its L2 residual on the way): the
+                                sweep the previous step's count expects to be the last runs unverified
+                                (a projection that needed one sweep runs that sweep and nothing else).
+                                If the advection finds the residual above tol, the advected field is
+                                dropped, the projection goes on with evaluations of its own and the
+                                advection is repeated (fs3d_stats.redone counts these).  Every
+                                projection still ends on a verified residual <= tol.  Needs
+                                FS_STOP_L2_RESIDUAL, red-black order, the sweeps solver, FS_ADVECT_TILED
+                                and semi-Lagrange; otherwise it acts as FS_CHECK_ADAPTIVE           */
 };
 
 /* implementation of one red-black sweep (same result bit for bit) */
@@ -154,6 +155,10 @@ typedef struct fs3d_stats {
     double ms_project;       /* device time of the last step's projections, milliseconds         */
     double ms_advect;        /* device time of the last step's advections (+ reflection)         */
     double ms_step;          /* device time of the whole last step                               */
+    int32_t evaluations_step;/* passes over the velocity that evaluated the stopping metric in the last
+                                step (an evaluation folded into an advection is not a pass)         */
+    int32_t redone;          /* advections repeated since reset because a deferred evaluation found
+                                the tolerance not met (FS_CHECK_DEFERRED)                           */
 } fs3d_stats;
 
 typedef struct fs3d_sim fs3d_sim;

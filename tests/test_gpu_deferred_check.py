@@ -52,6 +52,7 @@ def test_deferred_check_equals_every_sweep_check(fsamd, mode):
     b = ring(fsamd, n, check_every=fsamd.CHECK_DEFERRED, **cfg)
     counts = run_pair(fsamd, a, b, 14, 1.0 / 30.0, n=n)
     assert counts[-1][1] <= (2 if mode == 0 else 4), counts     # the regime the deferral is for
+    assert b.stats().evaluations_step == 0 and a.stats().evaluations_step >= 1   # no residual pass of its own left
     assert sum(c[1] for c in counts) <= sum(c[0] for c in counts) + 6, counts
 
 
@@ -63,6 +64,7 @@ def test_misprediction_is_rolled_back(fsamd):
     counts = run_pair(fsamd, a, b, 12, 1.0 / 30.0, n=n, disturb_at=(8,))
     assert counts[8][0] > counts[7][0] + 1, counts          # the kick did need more sweeps
     assert counts[8][1] == counts[8][0], counts             # and the deferred run found the same count
+    assert b.stats().redone >= 1                            # by repeating an advection
 
 
 def test_deferred_check_random_state_with_obstacles(fsamd):

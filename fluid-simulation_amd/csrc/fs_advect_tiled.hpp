@@ -101,20 +101,51 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     const int wl = (ty + R) * WX + tx + R;   // own cell inside the window
     constexpr int VF = SEP ? 4 : 0;          // first field of the carrying velocity
 
-    // A sample.  The eight LDS reads are unconditional (from the own cell when the backtrace left the
-    // window) so that the reads of all samples of a cell are in flight together; a sample outside the
-    // window then replaces them by global loads.
-    auto sample = [&](int f, const FastTrace<T, OFF>& tr, int z) -> T {
+    // Tiles and planes at least two cells away from the shell: every tap of a backtrace that ends inside the
+    // staged window is then one the reference reads, and the per-axis validity tests (and the zeroing of
+    // weights) are skipped.  All three are uniform over the workgroup.
+    const bool safe_x = x0 >= 2 && x0 + C::TX <= g.nx - 2, safe_y = y0 >= 2 && y0 + C::TY <= g.ny - 2;
+
+    // A sample of field f at the backtrace of (x, y, gz) along (dx, dy, dz).  The eight LDS reads are
+    // unconditional (from the own cell when the backtrace left the window) so that the reads of all samples of
+    // a cell are in flight together; a sample outside the window then takes the general path of the direct
+    // kernel: validity of every tap, clamped base address, global loads.
+    auto sample = [&](int f, T dx, T dy, T dz, int z, int gz, bool safe_z, bool& oob) -> T {
+        const T one = (T)1, zero = (T)0;
+        const T px = (T)x - dx * t_step, py = (T)y - dy * t_step, pz = (T)gz - dz * t_step;
+        const T bx = floor(px), by = floor(py), bz = floor(pz);
+        const T fu = px - bx, fv = py - by, fw = pz - bz;
+        const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
+        const bool far = !(fmax(fmax(fabs(bx), fabs(by)), fabs(bz)) < (T)8388608);
+        const int lzb = ibz - g.gz0;
+        const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(lzb - (z - R));
+        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R) && !far;
+        FastTrace<T, OFF> tr;
+        tr.far = false;
+        tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
+        // tap b is read when 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3 (main.cpp:411-435)
+        if (!safe_x) {
+            const uint32_t m = (uint32_t)(g.nx - 2);
+            tr.x0 = (uint32_t)ibx - 1u < m ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < m ? tr.x1 : zero;
+        }
+        if (!safe_y) {
+            const uint32_t m = (uint32_t)(g.ny - 2);
+            tr.y0 = (uint32_t)iby - 1u < m ? tr.y0 : zero; tr.y1 = (uint32_t)iby < m ? tr.y1 : zero;
+        }
+        if (!safe_z) {
+            const uint32_t m = (uint32_t)(g.gnz - 2);
+            tr.z0 = (uint32_t)ibz - 1u < m ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < m ? tr.z1 : zero;
+        }
         Taps<T> t;
-        const uint32_t ax = (uint32_t)(tr.cx - (x0 - R)), ay = (uint32_t)(tr.cy - (y0 - R)), az = (uint32_t)(tr.cz - (z - R));
-        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
         const int a = in ? (int)ay * WX + (int)ax : wl;
-        const int pz = in ? tr.cz : z;
-        const T* p0 = L + (f * NPL + (pz & (NPL - 1))) * PS + a;
-        const T* p1 = L + (f * NPL + ((pz + 1) & (NPL - 1))) * PS + a;
+        const int pl = in ? lzb : z;
+        const T* p0 = L + (f * NPL + (pl & (NPL - 1))) * PS + a;
+        const T* p1 = L + (f * NPL + ((pl + 1) & (NPL - 1))) * PS + a;
         t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[WX]; t.s[3] = p1[0];
         t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
         if (__builtin_expect(!in, 0)) {
+            tr = fast_prepare<T, OFF, SLAB>(g, x, y, gz, dx, dy, dz, t_step);
+            oob = oob || tr.oob;
             // volatile: keeps these loads apart from the LDS reads above (merged, the pair becomes one
             // generic-address load per tap, which is served at a fraction of the LDS rate)
             const volatile T* r00 = at_byte(src[f], trace_base(g, tr));
@@ -163,11 +194,10 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
             const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
             const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
-            const FastTrace<T, OFF> tu = fast_prepare<T, OFF, SLAB>(g, x, y, gz, u_c, uy, uz, t_step);
-            const FastTrace<T, OFF> tv = fast_prepare<T, OFF, SLAB>(g, x, y, gz, vx, v_c, vz, t_step);
-            const FastTrace<T, OFF> tw = fast_prepare<T, OFF, SLAB>(g, x, y, gz, wx, wy, w_c, t_step);
-            bool oob = fluid && (tu.oob || tv.oob || tw.oob);
-            const T su = sample(0, tu, z), sv = sample(1, tv, z), sw = sample(2, tw, z);
+            const bool safe_z = gz >= 2 && gz <= g.gnz - 3;
+            bool oob_v = false, oob_d = false;
+            const T su = sample(0, u_c, uy, uz, z, gz, safe_z, oob_v), sv = sample(1, vx, v_c, vz, z, gz, safe_z, oob_v),
+                    sw = sample(2, wx, wy, w_c, z, gz, safe_z, oob_v);
             if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
             // main.cpp:284-289
             T uc, vc, wc;
@@ -176,9 +206,9 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             } else {
                 uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
             }
-            const FastTrace<T, OFF> td = fast_prepare<T, OFF, SLAB>(g, x, y, gz, uc, vc, wc, t_step);
-            const T sd = sample(3, td, z);
-            if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || td.oob; }
+            const T sd = sample(3, uc, vc, wc, z, gz, safe_z, oob_d);
+            bool oob = fluid && oob_v;
+            if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || oob_d; }
             if (SLAB && oob) *oob_flag = 1;
         }
         *const_cast<T*>(at_byte<T, OFF>(ou, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(ov, i)) = nv;

@@ -460,19 +460,38 @@ __device__ __forceinline__ FastTrace<T, OFF> fast_prepare(const Grid& g, int x, 
     return tr;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// The eight terms of main.cpp:400-407 in their order, each weight grouped as (x*y)*z.  For 4-byte elements
+// the products are formed two at a time (packed multiplies: the same IEEE products, half the instructions);
+// the taps pair up the way the two-element LDS reads deliver them.
 template <typename T, typename OFF>
 __device__ __forceinline__ T fast_combine(const FastTrace<T, OFF>& tr, const Taps<T>& t) {
-    const T a00 = tr.x0 * tr.y0, a10 = tr.x1 * tr.y0, a01 = tr.x0 * tr.y1, a11 = tr.x1 * tr.y1;
-    T r = 0;
-    r += t.s[0] * (a00 * tr.z0);
-    r += t.s[1] * (a10 * tr.z0);
-    r += t.s[2] * (a01 * tr.z0);
-    r += t.s[3] * (a00 * tr.z1);
-    r += t.s[4] * (a11 * tr.z0);
-    r += t.s[5] * (a10 * tr.z1);
-    r += t.s[6] * (a01 * tr.z1);
-    r += t.s[7] * (a11 * tr.z1);
-    return r;
+    if constexpr (sizeof(T) == 4) {
+        const float2v xs = {tr.x0, tr.x1};
+        const float2v a0 = xs * float2v{tr.y0, tr.y0};   // a00, a10
+        const float2v a1 = xs * float2v{tr.y1, tr.y1};   // a01, a11
+        const float2v z0 = {tr.z0, tr.z0}, z1 = {tr.z1, tr.z1};
+        const float2v p01 = float2v{t.s[0], t.s[1]} * (a0 * z0);
+        const float2v p24 = float2v{t.s[2], t.s[4]} * (a1 * z0);
+        const float2v p35 = float2v{t.s[3], t.s[5]} * (a0 * z1);
+        const float2v p67 = float2v{t.s[6], t.s[7]} * (a1 * z1);
+        T r = 0;
+        r += p01.x; r += p01.y; r += p24.x; r += p35.x; r += p24.y; r += p35.y; r += p67.x; r += p67.y;
+        return r;
+    } else {
+        const T a00 = tr.x0 * tr.y0, a10 = tr.x1 * tr.y0, a01 = tr.x0 * tr.y1, a11 = tr.x1 * tr.y1;
+        T r = 0;
+        r += t.s[0] * (a00 * tr.z0);
+        r += t.s[1] * (a10 * tr.z0);
+        r += t.s[2] * (a01 * tr.z0);
+        r += t.s[3] * (a00 * tr.z1);
+        r += t.s[4] * (a11 * tr.z0);
+        r += t.s[5] * (a10 * tr.z1);
+        r += t.s[6] * (a01 * tr.z1);
+        r += t.s[7] * (a11 * tr.z1);
+        return r;
+    }
 }
 
 template <typename T, typename OFF>

@@ -17,6 +17,7 @@
 // arithmetic is that of k_advect, bit for bit.
 #pragma once
 #include "fs_kernels3d.hpp"
+#include <type_traits>
 
 namespace fsamd {
 
@@ -104,13 +105,15 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     // Tiles and planes at least two cells away from the shell: every tap of a backtrace that ends inside the
     // staged window is then one the reference reads, and the per-axis validity tests (and the zeroing of
     // weights) are skipped.  All three are uniform over the workgroup.
-    const bool safe_x = x0 >= 2 && x0 + C::TX <= g.nx - 2, safe_y = y0 >= 2 && y0 + C::TY <= g.ny - 2;
+    // The step of a safe tile and plane is compiled without them (SAFE), so that no trace of the tests is left.
+    const bool safe_xy = x0 >= 2 && x0 + C::TX <= g.nx - 2 && y0 >= 2 && y0 + C::TY <= g.ny - 2;
 
     // A sample of field f at the backtrace of (x, y, gz) along (dx, dy, dz).  The eight LDS reads are
     // unconditional (from the own cell when the backtrace left the window) so that the reads of all samples of
     // a cell are in flight together; a sample outside the window then takes the general path of the direct
     // kernel: validity of every tap, clamped base address, global loads.
-    auto sample = [&](int f, T dx, T dy, T dz, int z, int gz, bool safe_z, bool& oob) -> T {
+    auto sample = [&](auto safe_tag, int f, T dx, T dy, T dz, int z, int gz, bool& oob) -> T {
+        constexpr bool SAFE = decltype(safe_tag)::value;
         const T one = (T)1, zero = (T)0;
         const T px = (T)x - dx * t_step, py = (T)y - dy * t_step, pz = (T)gz - dz * t_step;
         const T bx = floor(px), by = floor(py), bz = floor(pz);
@@ -124,17 +127,11 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         tr.far = false;
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
         // tap b is read when 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3 (main.cpp:411-435)
-        if (!safe_x) {
-            const uint32_t m = (uint32_t)(g.nx - 2);
-            tr.x0 = (uint32_t)ibx - 1u < m ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < m ? tr.x1 : zero;
-        }
-        if (!safe_y) {
-            const uint32_t m = (uint32_t)(g.ny - 2);
-            tr.y0 = (uint32_t)iby - 1u < m ? tr.y0 : zero; tr.y1 = (uint32_t)iby < m ? tr.y1 : zero;
-        }
-        if (!safe_z) {
-            const uint32_t m = (uint32_t)(g.gnz - 2);
-            tr.z0 = (uint32_t)ibz - 1u < m ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < m ? tr.z1 : zero;
+        if constexpr (!SAFE) {
+            const uint32_t mx = (uint32_t)(g.nx - 2), my = (uint32_t)(g.ny - 2), mz = (uint32_t)(g.gnz - 2);
+            tr.x0 = (uint32_t)ibx - 1u < mx ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < mx ? tr.x1 : zero;
+            tr.y0 = (uint32_t)iby - 1u < my ? tr.y0 : zero; tr.y1 = (uint32_t)iby < my ? tr.y1 : zero;
+            tr.z0 = (uint32_t)ibz - 1u < mz ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < mz ? tr.z1 : zero;
         }
         Taps<T> t;
         const int a = in ? (int)ay * WX + (int)ax : wl;
@@ -168,7 +165,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     };
 
     double racc = 0;
-    auto compute = [&](int z, uint32_t fl) {
+    auto compute = [&](auto safe_tag, int z, uint32_t fl) {
         const int gz = z + g.gz0;
         const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
         const OFF i = e * (OFF)sizeof(T);
@@ -194,10 +191,9 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
             const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
             const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
-            const bool safe_z = gz >= 2 && gz <= g.gnz - 3;
             bool oob_v = false, oob_d = false;
-            const T su = sample(0, u_c, uy, uz, z, gz, safe_z, oob_v), sv = sample(1, vx, v_c, vz, z, gz, safe_z, oob_v),
-                    sw = sample(2, wx, wy, w_c, z, gz, safe_z, oob_v);
+            const T su = sample(safe_tag, 0, u_c, uy, uz, z, gz, oob_v), sv = sample(safe_tag, 1, vx, v_c, vz, z, gz, oob_v),
+                    sw = sample(safe_tag, 2, wx, wy, w_c, z, gz, oob_v);
             if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
             // main.cpp:284-289
             T uc, vc, wc;
@@ -206,7 +202,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             } else {
                 uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
             }
-            const T sd = sample(3, uc, vc, wc, z, gz, safe_z, oob_d);
+            const T sd = sample(safe_tag, 3, uc, vc, wc, z, gz, oob_d);
             bool oob = fluid && oob_v;
             if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || oob_d; }
             if (SLAB && oob) *oob_flag = 1;
@@ -227,7 +223,11 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         uint32_t fl = FL_SELF_OBJECT;
         if (mine) fl = flags[((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x];
         fetch(z + R + 1);
-        if (mine) compute(z, fl);
+        const int gz = z + g.gz0;
+        if (mine) {
+            if (safe_xy && gz >= 2 && gz <= g.gnz - 3) compute(std::true_type{}, z, fl);
+            else compute(std::false_type{}, z, fl);
+        }
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
         __syncthreads();
     }

@@ -496,27 +496,50 @@ int launch_fused_sweep(fs3d_sim* s) {
 // launch follows the total number of (row, plane) steps, not the number of busy CUs, so the tile keeps
 // the most rows a workgroup can have (the smallest share of halo rows) and the z-chunking only has to
 // provide about one workgroup per CU.
+// One launch of the rows kernel over `ntx` tiles of a row starting at column xbase (see the kernel for xedges).
 template <typename T, int NSEG, int CP>
-int launch_rows_sweep(fs3d_sim* s) {
+int launch_rows_tiles(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int ntx, int xbase, int xedges) {
     using C = RowsCfg<T, NSEG, CP>;
     auto kern = k_rb_rows<T, NSEG, CP>;
     SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
-    const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
     const int rows = std::min(C::RY, s->ny);
-    const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
     const int nty = s->ny <= rows ? 1 : div_up(s->ny - 4, rows - 4);
-    return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
-        FusedRanges r = fused_ranges<T>(p);
-        r.z0 = z0; r.z1 = z1;
-        // the narrow variants fit 64 registers: two workgroups of 16 waves share a CU
-        constexpr int per_cu = NSEG * CP * sizeof(T) <= 8 ? 2 : 1;
-        const int nchunks = pick_chunks(z1 - z0, ntx * nty, per_cu * s->num_cus);
-        r.zchunk = div_up(z1 - z0, nchunks);
-        dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
-        hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
-                           F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r, ntx, nty, rows);
+    FusedRanges r = fused_ranges<T>(p);
+    r.z0 = z0; r.z1 = z1;
+    // the narrow variants fit 64 registers: two workgroups of 16 waves share a CU
+    constexpr int per_cu = NSEG * CP * sizeof(T) <= 8 ? 2 : 1;
+    const int nchunks = pick_chunks(z1 - z0, ntx * nty, per_cu * s->num_cus);
+    r.zchunk = div_up(z1 - z0, nchunks);
+    dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
+    hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, r, ntx, nty, rows, xbase, xedges);
+    return FS_OK;
+}
+
+// The register-resident form (fs_sweep_rows.hpp); needs an even nx.  Measured at 512^3: the time of a
+// launch follows the total number of (row, plane) steps, not the number of busy CUs, so the tile keeps
+// the most rows a workgroup can have (the smallest share of halo rows) and the z-chunking only has to
+// provide about one workgroup per CU.  Tiles of W columns overlap by 4, so a row of nx columns takes
+// ceil((nx - 4) / (W - 4)) of them: where the last of these would hold few columns (nx = 1024 is two tiles
+// of 512 and four columns) it is given to a launch of a narrower variant instead, which marches through a
+// quarter of the lanes (1.17 -> 0.97 ms per sweep at 1024 x 1024 x 128).
+template <typename T, int NSEG, int CP>
+int launch_rows_sweep(fs3d_sim* s) {
+    using C = RowsCfg<T, NSEG, CP>;
+    const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 4, C::W - 4);
+    const int last_origin = (ntx - 1) * (C::W - 4), last_cols = s->nx - last_origin;
+    const bool split = ntx >= 2 && C::W > 128 && last_cols <= C::W / 2;
+    int rc = FS_OK;
+    auto keep = [&](int r) { if (rc == FS_OK) rc = r; };
+    const int drc = one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
+        if (!split) { keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ntx, 0, 3)); return; }
+        keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ntx - 1, 0, 1));
+        if (last_cols <= 128) keep(launch_rows_tiles<T, 1, 1>(s, p, z0, z1, st, 1, last_origin, 2));
+        else if (sizeof(T) == 4 && s->nx % 4 == 0) keep(launch_rows_tiles<T, 1, 2>(s, p, z0, z1, st, 1, last_origin, 2));
+        else keep(launch_rows_tiles<T, 2, 1>(s, p, z0, z1, st, 1, last_origin, 2));
     });
+    return rc != FS_OK ? rc : drc;
 }
 
 template <typename T>

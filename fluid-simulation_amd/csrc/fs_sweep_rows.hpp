@@ -52,7 +52,7 @@ template <typename T, int NSEG, int CP>
 __global__ void __launch_bounds__(1024, (NSEG * CP * sizeof(T) <= 8 ? 8 : 4))
 k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
-          FusedRanges r, int ntx, int nty, int rows) {
+          FusedRanges r, int ntx, int nty, int rows, int xbase, int xedges) {
     using C = RowsCfg<T, NSEG, CP>;
     constexpr int NQ = C::NQ;
     using VecT = Vec<T, 2 * CP>;
@@ -71,12 +71,15 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     const int xcd = lin & 7, qq = total >> 3, rem = total & 7;
     const int logical = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (lin >> 3);
     const int by = logical % nty, bx = (logical / nty) % ntx, bz = logical / (nty * ntx);
-    const int xr0 = bx * (C::W - 4), yr0 = by * (rows - 4);   // tile origin; tiles overlap by 4
+    // tile origin; tiles overlap by 4.  A launch may cover only some of the tiles of a row (the others being
+    // left to a launch of another tile width): xbase is the origin of its first tile, and xedges says whether
+    // its first (bit 0) and last (bit 1) tiles touch the domain boundary.
+    const int xr0 = xbase + bx * (C::W - 4), yr0 = by * (rows - 4);
     const int y = yr0 + ry;
     const bool row_in = y < g.ny;
     // the part of the tile this workgroup stores: everything but the two stale rings, except at the
     // domain boundary where there is no neighbour tile
-    const int cx_lo = bx == 0 ? 0 : xr0 + 2, cx_hi = bx == ntx - 1 ? g.nx : xr0 + C::W - 2;
+    const int cx_lo = (bx == 0 && (xedges & 1)) ? 0 : xr0 + 2, cx_hi = (bx == ntx - 1 && (xedges & 2)) ? g.nx : xr0 + C::W - 2;
     const int cy_lo = by == 0 ? 0 : yr0 + 2, cy_hi = by == nty - 1 ? g.ny : yr0 + rows - 2;
     const bool row_core = y >= cy_lo && y < cy_hi;
 

@@ -736,7 +736,9 @@ int mg_coarse_cycle(fs3d_sim* s, Part& p, size_t l) {
         S.n = 0;
         for (size_t k = l; k < p.mg.size() && S.n < 8; ++k) S.L[S.n++] = mg_level<T>(p.mg[k]);
         if ((size_t)S.n == p.mg.size() - l) {
-            hipLaunchKernelGGL((k_mg_small_cycle<T, 8>), dim3(1), dim3(1024), 0, s->stream, S, kMgNu1, kMgNu2, kMgBottom, (T)kMgAlpha);
+            const size_t lds = mg_small_lds_bytes(S);
+            SIM_HIP(allow_lds(s, (const void*)k_mg_small_cycle<T, 8>, lds));
+            hipLaunchKernelGGL((k_mg_small_cycle<T, 8>), dim3(1), dim3(1024), lds, s->stream, S, kMgNu1, kMgNu2, kMgBottom, (T)kMgAlpha);
             return FS_OK;
         }
     }

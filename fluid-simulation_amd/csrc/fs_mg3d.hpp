@@ -169,64 +169,142 @@ __global__ void k_mg_apply(Grid g, T* __restrict__ u, T* __restrict__ v, T* __re
     if (fl & FL_ZM) w[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, y / 2, (z - 1) / 2)]);
 }
 
-// The levels of at most a few thousand cells in one workgroup: the sub-cycle below a level costs ~80
-// launches of a few microseconds each when every colour of every sweep is a kernel of its own.  Same
-// operations in the same per-value order as the per-level kernels; colours and stages are separated by
-// workgroup barriers.
+// The levels of at most 4096 cells in one workgroup: the sub-cycle below a level costs ~80 launches of a
+// few microseconds each when every colour of every sweep is a kernel of its own, and ~80 round trips to L2
+// when one workgroup runs them on global arrays.  Here the errors e (and the restricted right-hand sides) of
+// all these levels live in LDS, and while a level is being smoothed every thread keeps the coefficients of
+// its (up to four) cells in registers, so a colour of a sweep is six LDS reads and a barrier.  Same
+// operations in the same per-value order as the per-level kernels.  Only e of the first level goes back
+// to global memory (the caller prolongs it).
 template <typename T, int MAXL>
 struct MgSmall { int n; MgLevel<T> L[MAXL]; };
 
 template <typename T, int MAXL>
+__host__ __device__ inline int mg_small_cells(const MgSmall<T, MAXL>& S, int l) { return S.L[l].d.nx * S.L[l].d.ny * S.L[l].d.nz; }
+template <typename T, int MAXL>
+inline size_t mg_small_lds_bytes(const MgSmall<T, MAXL>& S) {
+    size_t total = 0;
+    for (int l = 0; l < S.n; ++l) total += (size_t)mg_small_cells(S, l);
+    return (2 * total + (size_t)mg_small_cells(S, 0)) * sizeof(T);
+}
+
+template <typename T, int MAXL>
 __global__ void __launch_bounds__(1024)
 k_mg_small_cycle(MgSmall<T, MAXL> S, int nu1, int nu2, int nu_bottom, T alpha) {
+    constexpr int KMAX = 4, NT = 1024;   // cells per thread: levels hold at most KMAX * NT cells
+    extern __shared__ __align__(16) unsigned char mg_lds_raw[];
     const int tid = threadIdx.x;
-    auto cells = [](const MgDims& d) { return d.nx * d.ny * d.nz; };
-    auto smooth = [&](const MgLevel<T>& L, int sweeps) {
-        const int n = cells(L.d);
+    int total = 0;
+    for (int l = 0; l < S.n; ++l) total += mg_small_cells(S, l);
+    T* E = reinterpret_cast<T*>(mg_lds_raw);   // e of every level, one after the other
+    T* R = E + total;                          // r of every level but the first (same offsets)
+    T* RES = R + total;                        // residuals of the level being restricted
+    auto offset = [&](int l) { int o = 0; for (int k = 0; k < l; ++k) o += mg_small_cells(S, k); return o; };
+
+    // coefficients of this thread's cells on the level being worked on
+    T dg[KMAX], rr[KMAX], w[KMAX][6];
+    int mask[KMAX];   // bits 0-5: neighbour x-, x+, y-, y+, z-, z+ exists; bit 6: colour; bit 7: cell exists
+    int nx = 1, nxy = 1, n = 0;
+    T* e = E;
+    auto load = [&](int l) {
+        const MgLevel<T>& L = S.L[l];
+        nx = L.d.nx; nxy = L.d.nx * L.d.ny; n = nxy * L.d.nz;
+        e = E + offset(l);
+        const T* rl = R + offset(l);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * NT;
+            mask[k] = 0; dg[k] = 0; rr[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) w[k][j] = 0;
+            if (idx < n) {
+                const int x = idx % nx, y = (idx / nx) % L.d.ny, z = idx / nxy;
+                dg[k] = L.diag[idx];
+                rr[k] = l == 0 ? L.r[idx] : rl[idx];
+                w[k][0] = L.wx[idx]; w[k][1] = mg_at(L.d, L.wx, x + 1, y, z);
+                w[k][2] = L.wy[idx]; w[k][3] = mg_at(L.d, L.wy, x, y + 1, z);
+                w[k][4] = L.wz[idx]; w[k][5] = mg_at(L.d, L.wz, x, y, z + 1);
+                mask[k] = (x > 0) | (x < nx - 1) << 1 | (y > 0) << 2 | (y < L.d.ny - 1) << 3 | (z > 0) << 4 |
+                          (z < L.d.nz - 1) << 5 | ((x + y + z) & 1) << 6 | 1 << 7;
+            }
+        }
+    };
+    // sum over the six neighbours of weight * e in the order of mg_offdiag (e = 0 outside the level)
+    auto offdiag = [&](int k, int idx) {
+        const int m = mask[k];
+        T a = 0;
+        a += w[k][0] * ((m & 1) ? e[idx - 1] : (T)0);
+        a += w[k][1] * ((m & 2) ? e[idx + 1] : (T)0);
+        a += w[k][2] * ((m & 4) ? e[idx - nx] : (T)0);
+        a += w[k][3] * ((m & 8) ? e[idx + nx] : (T)0);
+        a += w[k][4] * ((m & 16) ? e[idx - nxy] : (T)0);
+        a += w[k][5] * ((m & 32) ? e[idx + nxy] : (T)0);
+        return a;
+    };
+    auto smooth = [&](int sweeps) {
         for (int it = 0; it < sweeps; ++it)
             for (int colour = 0; colour < 2; ++colour) {
-                for (int idx = tid; idx < n; idx += 1024) {
-                    const int x = idx % L.d.nx, y = (idx / L.d.nx) % L.d.ny, z = idx / (L.d.nx * L.d.ny);
-                    if (((x + y + z) & 1) != colour) continue;
-                    const T dg = L.diag[idx];
-                    if (dg > (T)0) L.e[idx] = (L.r[idx] + mg_offdiag(L, x, y, z)) / dg;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int idx = tid + k * NT;
+                    if ((mask[k] & 128) && ((mask[k] >> 6) & 1) == colour && dg[k] > (T)0)
+                        e[idx] = (rr[k] + offdiag(k, idx)) / dg[k];
                 }
                 __syncthreads();
             }
     };
+
     for (int l = 0; l < S.n; ++l) {
-        const MgLevel<T>& L = S.L[l];
-        for (int idx = tid; idx < cells(L.d); idx += 1024) L.e[idx] = 0;
+        load(l);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (mask[k] & 128) e[tid + k * NT] = 0;
         __syncthreads();
-        if (l == S.n - 1) { smooth(L, nu_bottom); break; }
-        smooth(L, nu1);
-        const MgLevel<T>& C = S.L[l + 1];
-        for (int idx = tid; idx < cells(C.d); idx += 1024) {
-            const int x = idx % C.d.nx, y = (idx / C.d.nx) % C.d.ny, z = idx / (C.d.nx * C.d.ny);
+        if (l == S.n - 1) { smooth(nu_bottom); break; }
+        smooth(nu1);
+        // r of level l+1 = sum over the 8 children (z, y, x order) of r - (diag*e - offdiag), cells without
+        // a diagonal contributing nothing
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * NT;
+            if (mask[k] & 128) RES[idx] = dg[k] > (T)0 ? rr[k] - (dg[k] * e[idx] - offdiag(k, idx)) : (T)0;
+        }
+        __syncthreads();
+        const MgDims fd = S.L[l].d, cd = S.L[l + 1].d;
+        T* rc = R + offset(l + 1);
+        for (int idx = tid; idx < cd.nx * cd.ny * cd.nz; idx += NT) {
+            const int x = idx % cd.nx, y = (idx / cd.nx) % cd.ny, z = idx / (cd.nx * cd.ny);
             T acc = 0;
             for (int c = 0; c < 2; ++c)
                 for (int b = 0; b < 2; ++b)
                     for (int a = 0; a < 2; ++a) {
                         const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;
-                        if (fx >= L.d.nx || fy >= L.d.ny || fz >= L.d.nz) continue;
-                        const int64_t i = mgi(L.d, fx, fy, fz);
-                        const T dg = L.diag[i];
-                        if (dg > (T)0) acc += L.r[i] - (dg * L.e[i] - mg_offdiag(L, fx, fy, fz));
+                        if (fx >= fd.nx || fy >= fd.ny || fz >= fd.nz) continue;
+                        acc += RES[(fz * fd.ny + fy) * fd.nx + fx];
                     }
-            C.r[idx] = acc;
+            rc[idx] = acc;
         }
         __syncthreads();
     }
     for (int l = S.n - 2; l >= 0; --l) {
-        const MgLevel<T>& L = S.L[l];
-        const MgLevel<T>& C = S.L[l + 1];
-        for (int idx = tid; idx < cells(L.d); idx += 1024) {
-            const int x = idx % L.d.nx, y = (idx / L.d.nx) % L.d.ny, z = idx / (L.d.nx * L.d.ny);
-            if (L.diag[idx] > (T)0) L.e[idx] += alpha * C.e[mgi(C.d, x / 2, y / 2, z / 2)];
+        load(l);
+        const MgDims fd = S.L[l].d, cd = S.L[l + 1].d;
+        const T* ec = E + offset(l + 1);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * NT;
+            if ((mask[k] & 128) && dg[k] > (T)0) {
+                const int x = idx % fd.nx, y = (idx / fd.nx) % fd.ny, z = idx / (fd.nx * fd.ny);
+                e[idx] += alpha * ec[((z / 2) * cd.ny + y / 2) * cd.nx + x / 2];
+            }
         }
         __syncthreads();
-        smooth(L, nu2);
+        smooth(nu2);
     }
+    // (the last smooth ends on a barrier, and e points at the first level again)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (mask[k] & 128) S.L[0].e[tid + k * NT] = e[tid + k * NT];
 }
 
 #undef FS_MG_CELL

@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--step-mode", type=int, default=1, help="0 reference step, 1 advection-reflection")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f32 = the reference's precision")
+    ap.add_argument("--advection", choices=["semi_lagrange", "maccormack"], default="semi_lagrange",
+                    help="maccormack: the correction and limiter of 3_fluid/FluidSim.cpp:217-389 after every advection")
     ap.add_argument("--scene", choices=["vortex_ring", "ring_collision", "smoke_plume"], default="vortex_ring")
     ap.add_argument("--grid", type=str, default="", help="nx,ny,nz override (e.g. 256,512,256 for the plume)")
     return ap.parse_args()
@@ -163,6 +165,7 @@ def main():
                         dtype=fs.F64 if a.dtype == "f64" else fs.F32,
                         stop_mode=fs.STOP_L2_RESIDUAL, tol=a.tol, max_iters=a.max_iters,
                         check_every=a.check_every, omega=a.omega, step_mode=a.step_mode, local_slabs=a.local_slabs, solver=1 if a.solver == "multigrid" else 0,
+                        advection=1 if a.advection == "maccormack" else 0,
                         buoyancy=1.0 if a.scene == "smoke_plume" else 0.0)
     scene_init, scene_step = scenes.SCENES[a.scene]
     scene_init(sim)
@@ -221,7 +224,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{a.scene.replace('_', ' ')} {nx}x{ny}x{nz}, dt 1/30, "
-                            f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step, red-black GS omega {a.omega:g}"
+                            f"{'advection-reflection' if a.step_mode == 1 else 'reference'} step"
+                            f"{' with MacCormack advection' if a.advection == 'maccormack' else ''}, red-black GS omega {a.omega:g}"
                             f"{' inside multigrid V(2,2) cycles' if a.solver == 'multigrid' else ''}, "
                             f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, "
                             + ("residual evaluated from one sweep before the previous step's count, then every sweep"
@@ -262,7 +266,8 @@ def main():
         if world == 1 and a.solver == "sweeps" and a.local_slabs == 1 and not a.no_multigrid_leg:
             line["solver_multigrid"] = multigrid_leg(fs, scenes, a, nx, ny, nz, device)
         big = (512, 512, 512)
-        if not a.no_512_leg and a.scene == "vortex_ring" and not a.n and not a.grid and a.dtype == "f32" and a.solver == "sweeps":
+        if not a.no_512_leg and a.scene == "vortex_ring" and not a.n and not a.grid and a.dtype == "f32" and a.solver == "sweeps" \
+                and a.advection == "semi_lagrange":
             # the configuration the multi-GPU lines are quoted on, on this rank's GPU alone (the other ranks wait):
             # with N = 1 it sits beside the 256^3 headline, with N > 1 it is the base of the strong-scaling ratio
             leg = extra_leg(fs, scenes, a, *big, device, 0, "vortex ring 512^3 on one GPU, same steps and stopping rule")

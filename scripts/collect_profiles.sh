@@ -7,7 +7,7 @@ set -e
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT   # (merged results of an earlier run with the same tag would be mixed in: use a fresh tag)
 cd /tmp && export TMPDIR=/tmp
 # the default command itself (256^3 headline + its multigrid and 512^3 legs; the CPU baseline adds no kernels)
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- \

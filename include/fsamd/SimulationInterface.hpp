@@ -4,8 +4,9 @@
 // adapters build without libigl, GLFW or OpenGL.
 //
 // A caller that has the reference tree uses the reference's own `Simulation`
-// as the adapter's base class instead; this mirror is
-// what the tests and headless drivers derive from.
+// as the adapter's base class instead (fsamd::FluidSim3DSimulation<Simulation>,
+// the template takes the base as its parameter); this mirror is what the tests
+// and headless drivers derive from.
 #pragma once
 #include <cstdint>
 

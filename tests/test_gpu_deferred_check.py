@@ -101,3 +101,21 @@ def test_deferred_check_falls_back_where_it_cannot_apply(fsamd):
         assert a.stats().sweeps_step == b.stats().sweeps_step
         for k in range(4):
             assert np.array_equal(a.get_field(k), b.get_field(k))
+
+
+def test_full_size_512_slabs_and_deferral(fsamd):
+    # the multi-GPU configuration's grid: eight z-slabs on this GPU against the single domain, three benchmark
+    # steps (sweeps capped at 40) with the deferred evaluation; fields bit for bit
+    n = 512
+    cfg = dict(stop_mode=2, tol=1e-6, max_iters=40, step_mode=1, check_every=fsamd.CHECK_DEFERRED)
+    a = ring(fsamd, n, **cfg)
+    b = ring(fsamd, n, local_slabs=8, **cfg)
+    for it in range(3):
+        for g in (a, b):
+            g.fill_sphere_influence(n / 10.0, it)
+            g.advance(1.0 / 30.0)
+        sa, sb = a.stats(), b.stats()
+        assert sa.sweeps_step == sb.sweeps_step and sb.metric == pytest.approx(sa.metric, rel=1e-9)
+    for k in range(4):
+        assert np.array_equal(a.get_field(k), b.get_field(k)), k
+    assert a.stats().sweeps_step >= 2

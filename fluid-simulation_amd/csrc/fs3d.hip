@@ -902,9 +902,8 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
 // generation's velocity into the other generation, then swaps generations.
 template <typename T, typename OFF, bool SLAB>
 int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, int cv, int ov, int cd, int od, T t_step,
-                  int density_mode, bool copy_to_tmp, bool reflect, bool with_res) {
-    // the owned planes, shell included, so that the new generation is complete
-    const int zb = p.H, ze = p.H + p.own_planes();
+                  int density_mode, bool copy_to_tmp, bool reflect, bool with_res, int zb, int ze) {
+    if (ze <= zb) return FS_OK;
     T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
     T* c1 = copy_to_tmp ? (T*)p.tmp[1] : nullptr;
     T* c2 = copy_to_tmp ? (T*)p.tmp[2] : nullptr;
@@ -926,16 +925,17 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         const int zchunk = div_up(ze - zb, nchunks);
         dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), div_up(ze - zb, zchunk));
         double* res_part = nullptr;
-        if (with_res) {
+        if (with_res) {   // the launches of one advection write their partials one after the other
             const size_t blocks = (size_t)g.x * g.y * g.z;
-            if (blocks > p.adv_cap) {
-                (void)hipFree(p.adv_part);
-                p.adv_part = nullptr; p.adv_cap = 0;
-                SIM_HIP(hipMalloc((void**)&p.adv_part, blocks * 2 * sizeof(double)));
-                p.adv_cap = blocks;
+            if (!p.adv_part) {
+                // at most planes/8 chunks per launch, three launches per advection
+                const size_t cap = (size_t)tiles * (size_t)(p.own_planes() / 8 + 6);
+                SIM_HIP(hipMalloc((void**)&p.adv_part, cap * 2 * sizeof(double)));
+                p.adv_cap = cap;
             }
-            p.adv_blocks = (int)blocks;
-            res_part = p.adv_part;
+            if (p.adv_blocks + blocks > p.adv_cap) return set_err(s, FS_ESTATE, "residual partials of the advection do not fit");
+            res_part = p.adv_part + 2 * (size_t)p.adv_blocks;
+            p.adv_blocks += (int)blocks;
         }
         hipLaunchKernelGGL(kern, g, b, lds, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0), F<T>(p, ov, 1),
                            F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob,
@@ -957,29 +957,50 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
     FS_TRY(prepare(s, HALO_ALL | (q_from_tmp ? HALO_TMP : 0)));
     const bool slab = s->nparts_global > 1;
     const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
-    for (Part& p : s->parts) {
-        const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
-        const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
-        const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
-        const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
-        if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
-        else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
-        else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
-        else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr)));
+    // The owned planes, shell included, so that the new generation is complete.  With several slabs the two
+    // planes next to every interface come first and their exchange starts at once, beside the advection of
+    // the slab interiors (pass 0: those planes, pass 1: the rest).
+    for (Part& p : s->parts) p.adv_blocks = 0;
+    for (int pass = slab ? 0 : 1; pass < 2; ++pass) {
+        for (Part& p : s->parts) {
+            const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
+            const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
+            const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
+            const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
+            const int a = p.H, b = p.H + p.own_planes();
+            const int lo_end = slab && p.has_lo ? std::min(a + p.H, b) : a;
+            const int hi_beg = slab && p.has_hi ? std::max(b - p.H, lo_end) : b;
+            const int ranges[3][2] = {{a, lo_end}, {hi_beg, b}, {lo_end, hi_beg}};
+            for (int r = pass == 0 ? 0 : 2; r < (pass == 0 ? 2 : 3); ++r) {
+                const int zb = ranges[r][0], ze = ranges[r][1];
+                if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
+                else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
+                else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
+                else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
+            }
+        }
+        SIM_HIP(hipGetLastError());
+        if (pass == 0) {
+            // the planes the neighbours need exist: send them (exchange_async queues behind what the main stream
+            // holds now; the base pointers of the exchange are those of the new generation)
+            s->curv = ov;
+            s->curd = od;
+            s->halo_dirty |= HALO_ALL | (copy_to_tmp ? HALO_TMP : 0);
+            FS_TRY(refresh_halos(s, HALO_ALL | HALO_TMP, true));
+        }
     }
-    SIM_HIP(hipGetLastError());
-    if (res_sum) {   // queued before the halo exchange, so that the host need not wait for that
+    if (!slab) {
+        s->curv = ov;
+        s->curd = od;
+        s->halo_dirty = 0;
+    }
+    if (res_sum) {
         for (int k = 0; k < s->nlocal; ++k)
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, s->parts[k].adv_part, s->parts[k].adv_blocks,
                                s->dres + 2 * k);
         SIM_HIP(hipGetLastError());
         FS_TRY(queue_reduction(s, false));
     }
-    s->curv = ov;
-    s->curd = od;
-    s->halo_dirty |= HALO_ALL | (copy_to_tmp ? HALO_TMP : 0);
-    // start the exchange of the new planes now; whoever needs them waits (join_halos)
-    FS_TRY(refresh_halos(s, HALO_ALL | HALO_TMP, true));
     if (res_sum) {
         SIM_HIP(hipStreamSynchronize(s->stream));
         *res_sum = s->hres[0];

@@ -9,9 +9,9 @@ reflection, half advection of the synthetic vortex-ring scene, with the projecti
 residual of 3_fluid/FluidSim.cpp:17-43 <= 1e-6 or the reference's cap of 1000 sweeps
 (advection-reflection/main.cpp:108); the residual is evaluated from one sweep before the count the
 previous step needed and then after every sweep (the reference evaluates it after every sweep); where
-that count was at most 3, the sweeps run unverified and the advection kernel that follows adds up the
-residual of the field it reads: every projection still ends on a verified residual <= tol, and a miss
-is redone with more sweeps.
+that count was small and steady, the last evaluation is left to the advection kernel that follows, which
+adds up the residual of the field it reads: every projection still ends on a verified residual <= tol,
+and a miss is redone with more sweeps.
 
 Workloads (BASELINE.json configs):
   N = 1   "Vortex ring 256^3 on one MI355X, GS to residual 1e-6, fp32"        (configs[1])
@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--max-iters", type=int, default=1000)
     ap.add_argument("--check-every", type=int, default=-1,
-                    help="n: residual after every n-th sweep; 0: adaptive schedule; -1: adaptive, and where the previous "
-                         "step needed <= 3 sweeps the advection that follows the projection evaluates the residual")
+                    help="n: residual after every n-th sweep; 0: adaptive schedule; -1: adaptive, and the last evaluation of a "
+                         "short, steady projection is made by the advection that follows it")
     ap.add_argument("--omega", type=float, default=1.0)
     ap.add_argument("--step-mode", type=int, default=1, help="0 reference step, 1 advection-reflection")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f32 = the reference's precision")
@@ -230,9 +230,10 @@ def main():
                             f"stop L2 residual <= {a.tol:g} or {a.max_iters} sweeps, "
                             + ("residual evaluated from one sweep before the previous step's count, then every sweep"
                                if a.check_every == 0 else
-                               "residual evaluated from one sweep before the previous step's count, then every sweep; a "
-                               "projection that needed <= 3 sweeps in the previous step is verified by the advection "
-                               "kernel that reads its result (redone with more sweeps if the residual exceeds the tolerance)"
+                               "residual evaluated from one sweep before the previous step's count, then every sweep; the last "
+                               "evaluation of a projection whose count was the same (<= 4) in the last two steps is made "
+                               "by the advection kernel that reads its result (redone with more sweeps if the residual "
+                               "exceeds the tolerance)"
                                if a.check_every == -1 else f"checked every {a.check_every}"),
                 "grid": [nx, ny, nz], "parallelism": f"z-slabs x{world}" + (f" (x{a.local_slabs} slabs per GPU)" if a.local_slabs > 1 else ""),
                 "sweeps_per_step": sweeps_per_step, "residual_passes_per_step": evals / a.steps,

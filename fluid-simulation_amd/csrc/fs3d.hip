@@ -1273,18 +1273,21 @@ int scatter_to(fs3d_sim* s, Part& p, const Stamp& st, int field, float scale, in
     const int n = (int)st.idx.size();
     if (!n) return FS_OK;
     int64_t* didx = nullptr; float* dval = nullptr;
-    SIM_HIP(hipMalloc((void**)&didx, n * sizeof(int64_t)));
-    SIM_HIP(hipMalloc((void**)&dval, n * sizeof(float)));
-    SIM_HIP(hipMemcpyAsync(didx, st.idx.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream));
-    SIM_HIP(hipMemcpyAsync(dval, st.val.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    if (field >= 0)
-        hipLaunchKernelGGL(k_scatter<T>, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, dval, scale, F<T>(p, field < 3 ? s->curv : s->curd, field));
-    if (cell_type >= 0)
-        hipLaunchKernelGGL(k_scatter_cells, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, (uint8_t)cell_type, p.cells);
-    SIM_HIP(hipGetLastError());
-    FS_TRY(quiesce(s));
+    hipError_t e = hipMalloc((void**)&didx, n * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&dval, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(didx, st.idx.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dval, st.val.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) {
+        if (field >= 0)
+            hipLaunchKernelGGL(k_scatter<T>, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, dval, scale, F<T>(p, field < 3 ? s->curv : s->curd, field));
+        if (cell_type >= 0)
+            hipLaunchKernelGGL(k_scatter_cells, dim3(div_up(n, 256)), dim3(256), 0, s->stream, n, didx, (uint8_t)cell_type, p.cells);
+        e = hipGetLastError();
+    }
+    const int rc = e == hipSuccess ? quiesce(s) : FS_OK;   // the host vectors and the device copies must outlive the kernels
     (void)hipFree(didx); (void)hipFree(dval);
-    return FS_OK;
+    SIM_HIP(e);
+    return rc;
 }
 
 template <typename T>

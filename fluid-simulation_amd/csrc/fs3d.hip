@@ -1069,7 +1069,7 @@ int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
 // Returns -1: no deferral; 0: deferral of the last evaluation only; 1: one sweep, unverified.
 int deferral(fs3d_sim* s, int slot, bool mac) {
     const fs3d_config& c = s->cfg;
-    if (c.check_every != FS_CHECK_DEFERRED || c.stop_mode != FS_STOP_L2_RESIDUAL || c.solver != FS_SOLVER_SWEEPS ||
+    if (c.check_every != FS_CHECK_DEFERRED || c.stop_mode != FS_STOP_L2_RESIDUAL ||
         c.ordering != FS_ORDER_RED_BLACK || c.advect_kernel != FS_ADVECT_TILED || mac)
         return -1;
     if (s->spec_backoff[slot] > 0) { --s->spec_backoff[slot]; return -1; }
@@ -1078,6 +1078,7 @@ int deferral(fs3d_sim* s, int slot, bool mac) {
     // and where an evaluation is a good part of the projection's cost (at twenty sweeps the count wanders by one
     // from step to step, and one evaluation in three is not worth the risk)
     if (h >= c.max_iters || h != s->sweep_hint_prev[slot] || h > 4) return -1;
+    if (c.solver == FS_SOLVER_MULTIGRID) return h == 1 ? 1 : -1;   // a cycle is evaluated by the solver itself
     return h > 1 ? 0 : 1;
 }
 

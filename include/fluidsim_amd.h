@@ -80,8 +80,9 @@ enum {
                                 dropped, the projection goes on with evaluations of its own and the
                                 advection is repeated (fs3d_stats.redone counts these).  Every
                                 projection still ends on a verified residual <= tol.  Needs
-                                FS_STOP_L2_RESIDUAL, red-black order, the sweeps solver, FS_ADVECT_TILED
-                                and semi-Lagrange; otherwise it acts as FS_CHECK_ADAPTIVE           */
+                                FS_STOP_L2_RESIDUAL, red-black order, FS_ADVECT_TILED and semi-Lagrange
+                                (under FS_SOLVER_MULTIGRID only projections of one sweep defer);
+                                otherwise it acts as FS_CHECK_ADAPTIVE                              */
 };
 
 /* implementation of one red-black sweep (same result bit for bit) */

@@ -13,12 +13,13 @@ for ce in ces:
                         check_every=ce, step_mode=1, solver=1 if 'mg' in sys.argv else 0)
     init, per_step = scenes.SCENES["vortex_ring"]
     init(sim)
-    out, ev = [], []
+    out, ev, ms = [], [], []
     for it in range(steps):
         per_step(sim, it)
         sim.advance(1.0 / 30.0)
         out.append(sim.stats().sweeps_step)
         ev.append(sim.stats().evaluations_step)
+        ms.append(round(sim.stats().ms_step, 2))
     sim.synchronize()
-    print("check_every", ce, out, "residual passes", ev, "redone", sim.stats().redone, flush=True)
+    print("check_every", ce, out, "residual passes", ev, "redone", sim.stats().redone, "device ms", ms, flush=True)
     sim.close()

@@ -32,6 +32,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifndef REAL
 #define REAL float
@@ -97,6 +100,18 @@ real *o3_field(O3 *o, int which) {
 }
 uint8_t *o3_cells(O3 *o) { return o->s; }
 int o3_real_bytes(void) { return (int)sizeof(real); }
+
+/* Threads the order-independent loops (red-black half-sweeps, advection, reflection) run on: results do not
+ * depend on it.  n > 0 sets it; returns the count in effect (1 in a build without OpenMP). */
+int o3_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 #define FOR_INTERIOR(o)                                   \
     for (int z = 1; z < (o)->nz - 1; z++)                 \
@@ -333,6 +348,7 @@ int o3_update(O3 *o, real t_step, real change_tol, int max_iter, real *last_chan
  * one colour own disjoint face sets, so the visiting order inside a colour is
  * irrelevant and a parallel execution gives bitwise the same field. */
 void o3_rb_halfsweep(O3 *o, int colour, real omega) {
+#pragma omp parallel for schedule(static)
     FOR_INTERIOR(o) {
         if (((x + y + z) & 1) == colour) gsp_visit(o, x, y, z, omega);
     }
@@ -409,6 +425,9 @@ void o3_advect(const O3 *o, real t_step, const real *qu, const real *qv, const r
     const int64_t n = o3_n(o);
     memcpy(ou, qu, n * sizeof(real)); memcpy(ov, qv, n * sizeof(real));
     memcpy(ow, qw, n * sizeof(real)); memcpy(od, qd, n * sizeof(real));
+    /* every output element is written by one iteration from inputs only (and, in density_mode 1, from the
+     * cell's own new faces): planes can go to different threads */
+#pragma omp parallel for schedule(static)
     FOR_INTERIOR(o) {
         const int64_t i = IDX(o, x, y, z);
         if (o->s[i] == CELL_FLUID) {
@@ -746,6 +765,7 @@ void o3_mg_vcycle(O3 *o, int nu1, int nu2, int nu_bottom, real alpha, int nlev_m
 /* Reflection of the unprojected field about the projected one (Zehnder et
  * al. 2018, Alg. 1): out = 2*proj - tilde, on every element. */
 void o3_reflect(int64_t n, const real *proj, const real *tilde, real *out) {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) out[i] = R(2.0) * proj[i] - tilde[i];
 }
 

@@ -32,6 +32,8 @@ def _lib(dtype):
     real = C.c_float if dtype is np.float32 else C.c_double
     P = C.c_void_p
     lib.o3_create.restype = P
+    lib.o3_threads.argtypes = [C.c_int]
+    lib.o3_threads.restype = C.c_int
     lib.o3_create.argtypes = [C.c_int] * 3
     lib.o3_destroy.argtypes = [P]
     lib.o3_field.restype = P

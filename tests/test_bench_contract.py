@@ -25,6 +25,8 @@ def test_arguments_and_defaults(monkeypatch):
 
 def test_cpu_baseline_leg_reports_the_contract_fields():
     bench = load_bench()
-    r = bench.cpu_baseline(24, 12.0, sample_sweeps=2)
+    r = bench.cpu_baseline(24, 12.0, sample_sweeps=2, threads=1)
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "Mcells/s"
     assert r["value"] > 0 and "sweeps" in r["sample"]
+    r = bench.cpu_baseline(24, 12.0, sample_sweeps=2, threads=2)
+    assert r["cores"] == 2 and "2 threads" in r["sample"]

@@ -224,3 +224,25 @@ def test_maccormack_limiter_and_second_order():
     err_mc = np.abs(m[3][core, core, core] - exact[None, None, core]).max()
     assert err_mc < 0.35 * err_sl
     assert m[3].max() <= d.max() and m[3][1:-1, 1:-1, 1:-1].min() >= 0.0
+
+
+def test_threads_do_not_change_a_bit():
+    # the red-black half-sweeps, the advection and the reflection run on OpenMP threads in the CPU baseline leg
+    rng = np.random.default_rng(77)
+    shape = (14, 12, 18)
+    out = []
+    for threads in (1, 3):
+        o = Oracle3D(shape[2], shape[1], shape[0])
+        assert o.lib.o3_threads(threads) == threads
+        r = np.random.default_rng(5)
+        o.cells[...] = random_cells(shape, r)
+        for k in range(4):
+            o.field(k)[...] = random_field(shape, r, np.float32, 3.0)
+        o.project_rb(stop_mode=0, max_iter=3)
+        s0 = [o.field(k).copy() for k in range(4)]
+        half = o.advect(0.02, s0, s0[:3], 1)
+        refl = [o.reflect(s0[k], half[k]) for k in range(3)]
+        out.append([o.field(k).copy() for k in range(4)] + list(half) + refl)
+        o.lib.o3_threads(1)
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)

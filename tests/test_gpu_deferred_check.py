@@ -69,8 +69,8 @@ def test_misprediction_is_rolled_back(fsamd):
 
 def test_deferred_check_random_state_with_obstacles(fsamd):
     # random masks (Object / StaticFluid cells inside), both generations of every field in play
-    _, a = make_pair(fsamd, 30, 22, 26, seed=3, scale=0.05, check_every=1, tol=5e-3, **CFG)
-    _, b = make_pair(fsamd, 30, 22, 26, seed=3, scale=0.05, check_every=-1, tol=5e-3, **CFG)
+    _, a = make_pair(fsamd, 140, 27, 14, seed=3, scale=0.05, check_every=1, tol=5e-3, **CFG)
+    _, b = make_pair(fsamd, 140, 27, 14, seed=3, scale=0.05, check_every=-1, tol=5e-3, **CFG)
     run_pair(fsamd, a, b, 8, 0.02)
 
 

@@ -231,10 +231,13 @@ def test_reflection_step_matches_oracle(fsamd, kernel):
 
 @pytest.mark.parametrize("kernel", [0, 1], ids=["tiled", "direct"])
 @pytest.mark.parametrize("scale", [20.0, 90.0])
-def test_reflection_step_random_state_matches_oracle(fsamd, kernel, scale):
+@pytest.mark.parametrize("shape", [(70, 19, 13), (140, 27, 12)])
+def test_reflection_step_random_state_matches_oracle(fsamd, kernel, scale, shape):
     # random masks and velocities; at scale 90 a half step moves up to 1.5 cells, so part of the samples
-    # leave the window the tiled kernel stages and the reflected field is formed from direct loads
-    o, g = make_pair(fsamd, 70, 19, 13, seed=21, scale=scale, step_mode=1, tol=50.0, max_iters=30, advect_kernel=kernel)
+    # leave the window the tiled kernel stages and the reflected field is formed from direct loads.  The
+    # second shape holds a tile and planes two cells away from the shell on every side, where the tiled kernel
+    # runs its step without tap-validity code.
+    o, g = make_pair(fsamd, *shape, seed=21, scale=scale, step_mode=1, tol=50.0, max_iters=30, advect_kernel=kernel)
     for step in range(2):
         reflection_step_oracle(o, 1.0 / 30.0, 50.0, 30)
         g.advance(1.0 / 30.0)

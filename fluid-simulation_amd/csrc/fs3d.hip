@@ -804,9 +804,9 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
     const int first = resume_from > 0 ? resume_from + 1 : adaptive ? std::max(1, hint - 1) : 1;
     // two early evaluations, at a quarter and at half of the expected count: a count that collapses (the step
     // after a start-up transient) is then found within a step or two, and a stale hint cannot cost much
-    // past the expected count the evaluations thin out (every sweep for eight sweeps, then one sweep in nine
+    // past the expected count the evaluations thin out (every sweep for four sweeps, then one sweep in five
     // of the excess): a projection that runs far beyond its hint, such as the first of a run, is not charged
-    // an evaluation per sweep, and overshoots its stopping sweep by at most an eighth of that excess
+    // an evaluation per sweep, and overshoots its stopping sweep by at most a quarter of that excess
     // (not while the count is steady: within an eighth of the one before)
     const bool steady = std::abs(hint - s->sweep_hint_prev[slot & 1]) <= std::max(1, hint / 8);
     const int early1 = steady ? 0 : first / 4, early2 = steady ? 0 : first / 2;
@@ -814,7 +814,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
         if (done < early1) return early1;
         if (done < early2) return early2;
         if (done < first) return first;
-        return done + 1 + (done - first) / 8;
+        return done + 1 + (done - first) / 4;
     };
     int next_check = check_after(resume_from);
     int it = resume_from;

@@ -688,11 +688,57 @@ MgLevel<T> mg_level(const Part::MgRaw& r) {
     return L;
 }
 
+// The coarse levels span the whole grid and live with the first local part.  With several slabs every rank
+// holds (and solves) all of them: a slab contributes the planes of level 1 that its own fine planes make up
+// (weights once, right-hand side per cycle), ranks swap those planes, and everything below level 1 is
+// computed redundantly, identically, everywhere.  The fine level, where the work is, stays distributed.
+
+// A slab's level-1 cells must be made of its own fine cells: every slab starts on an even plane.
+inline bool mg_slabs_ok(int nz, int nparts) {
+    for (int gp = 0; gp < nparts; ++gp) {
+        int z0, z1;
+        split_planes(nz, nparts, gp, &z0, &z1);
+        if (z0 % 2 != 0) return false;
+    }
+    return true;
+}
+
+// Level-1 planes made of the fine planes [z0, z1) (z0 even).
+inline void mg_coarse_planes(int z0, int z1, int* c0, int* c1) { *c0 = z0 / 2; *c1 = (z1 + 1) / 2; }
+
+// Every rank sends its planes of a level-1 array to every other rank and receives theirs in place.
+int mg_allgather_level1(fs3d_sim* s, void* base, const Part::MgRaw& L) {
+    if (s->nranks == 1) return FS_OK;
+    FS_TRY(join_halos(s));   // one stream at a time on the communicator
+    Rccl* R = s->rccl;
+    const size_t plane = (size_t)L.nx * L.ny * s->esz;
+    auto range_of = [&](int rank, int* c0, int* c1) {
+        int z0, z1, t;
+        split_planes(s->nz, s->nparts_global, rank * s->nlocal, &z0, &t);
+        split_planes(s->nz, s->nparts_global, (rank + 1) * s->nlocal - 1, &t, &z1);
+        mg_coarse_planes(z0, z1, c0, c1);
+    };
+    int m0, m1;
+    range_of(s->rank, &m0, &m1);
+    FS_TRY(nccl_check(s, R->GroupStart(), "ncclGroupStart"));
+    for (int r = 0; r < s->nranks; ++r) {
+        if (r == s->rank) continue;
+        int c0, c1;
+        range_of(r, &c0, &c1);
+        FS_TRY(nccl_check(s, R->Send((char*)base + (size_t)m0 * plane, (size_t)(m1 - m0) * plane, ncclUint8, r, s->comm, s->stream), "ncclSend"));
+        FS_TRY(nccl_check(s, R->Recv((char*)base + (size_t)c0 * plane, (size_t)(c1 - c0) * plane, ncclUint8, r, s->comm, s->stream), "ncclRecv"));
+    }
+    return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
+}
+
 template <typename T>
-int mg_prepare(fs3d_sim* s, Part& p) {
+int mg_prepare(fs3d_sim* s) {
+    Part& p = s->parts[0];
     auto grid_of = [](const Part::MgRaw& r, dim3* b, dim3* g) { *b = dim3(64, 4, 1); *g = dim3(div_up(r.nx, 64), div_up(r.ny, 4), r.nz); };
     if (p.mg.empty()) {
-        int nx = s->nx, ny = s->ny, nz = p.g.nzl;
+        for (Part& q : s->parts)
+            if (q.z0 % 2 != 0) return set_err(s, FS_EINVAL, "the multigrid solver needs slabs that start on even planes");
+        int nx = s->nx, ny = s->ny, nz = s->nz;
         while (p.mg.size() < 16) {
             nx = (nx + 1) / 2; ny = (ny + 1) / 2; nz = (nz + 1) / 2;
             Part::MgRaw r{nx, ny, nz, {nullptr}};
@@ -706,11 +752,19 @@ int mg_prepare(fs3d_sim* s, Part& p) {
         p.mg_weights_ok = false;
     }
     if (p.mg_weights_ok) return FS_OK;
+    for (Part& q : s->parts) {   // level-1 weights of the planes this slab makes up (its cell halos are current)
+        int c0, c1;
+        mg_coarse_planes(q.z0, q.z1, &c0, &c1);
+        const Part::MgRaw& r = p.mg[0];
+        dim3 b(64, 4, 1), g(div_up(r.nx, 64), div_up(r.ny, 4), c1 - c0);
+        hipLaunchKernelGGL(k_mg_weights_cells<T>, g, b, 0, s->stream, q.g, q.cells, mg_level<T>(r), c0);
+    }
+    SIM_HIP(hipGetLastError());
+    for (int k = 0; k < 3; ++k) FS_TRY(mg_allgather_level1(s, p.mg[0].a[k], p.mg[0]));
     for (size_t l = 0; l < p.mg.size(); ++l) {
         dim3 b, g;
         grid_of(p.mg[l], &b, &g);
-        if (l == 0) hipLaunchKernelGGL(k_mg_weights_cells<T>, g, b, 0, s->stream, p.g, p.cells, mg_level<T>(p.mg[0]));
-        else hipLaunchKernelGGL(k_mg_weights_level<T>, g, b, 0, s->stream, mg_level<T>(p.mg[l - 1]), mg_level<T>(p.mg[l]));
+        if (l > 0) hipLaunchKernelGGL(k_mg_weights_level<T>, g, b, 0, s->stream, mg_level<T>(p.mg[l - 1]), mg_level<T>(p.mg[l]));
         hipLaunchKernelGGL(k_mg_diag<T>, g, b, 0, s->stream, mg_level<T>(p.mg[l]));
     }
     SIM_HIP(hipGetLastError());
@@ -753,21 +807,41 @@ int mg_coarse_cycle(fs3d_sim* s, Part& p, size_t l) {
     return mg_smooth<T>(s, r, kMgNu2);
 }
 
-// One V-cycle on the current velocity (single slab, red-black order).
+// One V-cycle on the current velocity (red-black order).
 template <typename T>
 int mg_vcycle(fs3d_sim* s) {
     Part& p = s->parts[0];
-    FS_TRY(mg_prepare<T>(s, p));
+    const bool slabs = s->nparts_global > 1;
+    const bool one_pass = s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
+    FS_TRY(mg_prepare<T>(s));
     for (int k = 0; k < kMgNu1; ++k) FS_TRY(sweep_once<T>(s));
+    if (slabs) {   // the residual of a slab's top plane reads w of its first halo plane
+        halos_after_sweeps(s);
+        FS_TRY(refresh_halos(s, HALO_VEL));
+    }
     const Part::MgRaw& c = p.mg[0];
-    dim3 b(64, 4, 1), gc(div_up(c.nx, 64), div_up(c.ny, 4), c.nz);
-    hipLaunchKernelGGL(k_mg_fine_residual<T>, gc, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
-                       F<T>(p, s->curv, 2), p.flags, mg_level<T>(c));
-    FS_TRY(mg_coarse_cycle<T>(s, p, 0));
-    dim3 gf(div_up(s->nx - 2, 64), div_up(s->ny - 2, 4), p.g.nzl - 2);
-    hipLaunchKernelGGL(k_mg_apply<T>, gf, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1), F<T>(p, s->curv, 2),
-                       p.flags, mg_level<T>(c), (T)kMgAlpha);
+    dim3 b(64, 4, 1);
+    for (Part& q : s->parts) {
+        int c0, c1;
+        mg_coarse_planes(q.z0, q.z1, &c0, &c1);
+        dim3 gc(div_up(c.nx, 64), div_up(c.ny, 4), c1 - c0);
+        hipLaunchKernelGGL(k_mg_fine_residual<T>, gc, b, 0, s->stream, q.g, F<T>(q, s->curv, 0), F<T>(q, s->curv, 1),
+                           F<T>(q, s->curv, 2), q.flags, mg_level<T>(c), c0);
+    }
     SIM_HIP(hipGetLastError());
+    FS_TRY(mg_allgather_level1(s, c.a[5], c));
+    FS_TRY(mg_coarse_cycle<T>(s, p, 0));
+    for (Part& q : s->parts) {
+        if (q.ze <= q.zb) continue;
+        dim3 gf(div_up(s->nx - 2, 64), div_up(s->ny - 2, 4), q.ze - q.zb);
+        hipLaunchKernelGGL(k_mg_apply<T>, gf, b, 0, s->stream, q.g, F<T>(q, s->curv, 0), F<T>(q, s->curv, 1), F<T>(q, s->curv, 2),
+                           q.flags, mg_level<T>(c), (T)kMgAlpha, q.zb);
+    }
+    SIM_HIP(hipGetLastError());
+    if (slabs) {   // the corrected planes next to the interfaces go to the neighbours before the sweeps read them
+        s->halo_dirty |= HALO_VEL;
+        FS_TRY(refresh_halos(s, HALO_VEL, one_pass));
+    }
     for (int k = 0; k < kMgNu2; ++k) FS_TRY(sweep_once<T>(s));
     return FS_OK;
 }
@@ -1375,8 +1449,8 @@ bool config_ok(const fs3d_config* c, std::string* why) {
     if (c->sweep_kernel < FS_SWEEP_FUSED || c->sweep_kernel > FS_SWEEP_FUSED_LDS) { *why = "bad sweep_kernel"; return false; }
     if (c->advect_kernel < FS_ADVECT_TILED || c->advect_kernel > FS_ADVECT_DIRECT) { *why = "bad advect_kernel"; return false; }
     if (c->solver < FS_SOLVER_SWEEPS || c->solver > FS_SOLVER_MULTIGRID) { *why = "bad solver"; return false; }
-    if (c->solver == FS_SOLVER_MULTIGRID && (c->ordering != FS_ORDER_RED_BLACK || c->local_slabs > 1)) {
-        *why = "the multigrid solver needs red-black ordering and a single slab";
+    if (c->solver == FS_SOLVER_MULTIGRID && c->ordering != FS_ORDER_RED_BLACK) {
+        *why = "the multigrid solver needs red-black ordering";
         return false;
     }
     if (c->solver == FS_SOLVER_MULTIGRID && c->stop_mode == FS_STOP_L1_CHANGE) {
@@ -1397,7 +1471,7 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     std::string why;
     if (nx < 3 || ny < 3 || nz < 3 || !config_ok(&cfg, &why) || rank < 0 || rank >= nranks) return FS_EINVAL;
     if (cfg.ordering == FS_ORDER_LEXICOGRAPHIC && (nranks > 1 || cfg.local_slabs > 1)) return FS_EINVAL;
-    if (cfg.solver == FS_SOLVER_MULTIGRID && nranks > 1) return FS_EINVAL;
+    if (cfg.solver == FS_SOLVER_MULTIGRID && !mg_slabs_ok(nz, nranks * cfg.local_slabs)) return FS_EINVAL;
     fs3d_sim* s = new (std::nothrow) fs3d_sim();
     if (!s) return FS_ENOMEM;
     *out = s;   // handed back even on failure so that the caller can read the error text, then destroy
@@ -1589,8 +1663,8 @@ int fs3d_set_config(fs3d_sim* s, const fs3d_config* c) {
         return set_err(s, FS_EINVAL, "dtype and local_slabs are fixed at creation");
     if (c->ordering == FS_ORDER_LEXICOGRAPHIC && s->nparts_global > 1)
         return set_err(s, FS_EINVAL, "lexicographic order needs a single slab");
-    if (c->solver == FS_SOLVER_MULTIGRID && s->nparts_global > 1)
-        return set_err(s, FS_EINVAL, "the multigrid solver needs a single slab");
+    if (c->solver == FS_SOLVER_MULTIGRID && !mg_slabs_ok(s->nz, s->nparts_global))
+        return set_err(s, FS_EINVAL, "the multigrid solver needs slabs that start on even planes");
     const int dev = s->cfg.device;
     s->cfg = *c;
     s->cfg.device = dev;
@@ -1820,8 +1894,8 @@ int fs3d_advance(fs3d_sim* s, double dt) {
 
 int fs3d_mg_vcycle(fs3d_sim* s) {
     SIM_GUARD(s);
-    if (s->nparts_global != 1 || s->cfg.ordering != FS_ORDER_RED_BLACK)
-        return set_err(s, FS_ESTATE, "the multigrid cycle needs red-black ordering and a single slab");
+    if (s->cfg.ordering != FS_ORDER_RED_BLACK || !mg_slabs_ok(s->nz, s->nparts_global))
+        return set_err(s, FS_ESTATE, "the multigrid cycle needs red-black ordering and slabs that start on even planes");
     FS_TRY(prepare(s));
     return DISPATCH(s, mg_vcycle, s);
 }

@@ -41,20 +41,26 @@ __device__ __forceinline__ T mg_at(const MgDims& d, const T* a, int x, int y, in
     const int z = blockIdx.z;                                    \
     if (x >= (d).nx || y >= (d).ny) return;
 
-// level-1 weights from the fine cell types (cells: 0 = Fluid)
+// level-1 weights from the fine cell types (cells: 0 = Fluid).  The level-1 arrays span the whole grid; a launch
+// fills the planes from zc0 on (blockIdx.z counts them) from one slab's cells, whose local plane 0 is the global
+// plane g.gz0 (a slab starts on an even plane, so the children of its level-1 cells are its own; the cells
+// below a child, read for wz, are at worst in its halo).
 template <typename T>
-__global__ void k_mg_weights_cells(Grid g, const uint8_t* __restrict__ cells, MgLevel<T> L) {
-    FS_MG_CELL(L.d)
-    auto fluid = [&](int fx, int fy, int fz) { return cells[gidx(g, fx, fy, fz)] == 0; };
+__global__ void k_mg_weights_cells(Grid g, const uint8_t* __restrict__ cells, MgLevel<T> L, int zc0) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z + zc0;
+    if (x >= L.d.nx || y >= L.d.ny) return;
+    auto fluid = [&](int fx, int fy, int fz) { return cells[gidx(g, fx, fy, fz - g.gz0)] == 0; };   // fz global
     T wx = 0, wy = 0, wz = 0;
     for (int b = 0; b < 2; ++b)
         for (int a = 0; a < 2; ++a) {
             int fx = 2 * x, fy = 2 * y + a, fz = 2 * z + b;
-            if (fx >= 1 && fx < g.nx && fy < g.ny && fz < g.nzl && fluid(fx, fy, fz) && fluid(fx - 1, fy, fz)) wx += 1;
+            if (fx >= 1 && fx < g.nx && fy < g.ny && fz < g.gnz && fluid(fx, fy, fz) && fluid(fx - 1, fy, fz)) wx += 1;
             fx = 2 * x + a; fy = 2 * y; fz = 2 * z + b;
-            if (fy >= 1 && fy < g.ny && fx < g.nx && fz < g.nzl && fluid(fx, fy, fz) && fluid(fx, fy - 1, fz)) wy += 1;
+            if (fy >= 1 && fy < g.ny && fx < g.nx && fz < g.gnz && fluid(fx, fy, fz) && fluid(fx, fy - 1, fz)) wy += 1;
             fx = 2 * x + a; fy = 2 * y + b; fz = 2 * z;
-            if (fz >= 1 && fz < g.nzl && fx < g.nx && fy < g.ny && fluid(fx, fy, fz) && fluid(fx, fy, fz - 1)) wz += 1;
+            if (fz >= 1 && fz < g.gnz && fx < g.nx && fy < g.ny && fluid(fx, fy, fz) && fluid(fx, fy, fz - 1)) wz += 1;
         }
     const int64_t i = mgi(L.d, x, y, z);
     L.wx[i] = wx; L.wy[i] = wy; L.wz[i] = wz;
@@ -133,18 +139,22 @@ __global__ void k_mg_prolong(MgLevel<T> F, MgLevel<T> C, T alpha) {
     if (F.diag[i] > (T)0) F.e[i] += alpha * C.e[mgi(C.d, x / 2, y / 2, z / 2)];
 }
 
-// level-1 right-hand side: -div summed over the Fluid children (z, y, x order) of every level-1 cell
+// level-1 right-hand side: -div summed over the Fluid children (z, y, x order) of every level-1 cell; the
+// planes from zc0 on, from one slab's velocity (see k_mg_weights_cells)
 template <typename T>
 __global__ void k_mg_fine_residual(Grid g, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ w,
-                                   const uint8_t* __restrict__ flags, MgLevel<T> C) {
-    FS_MG_CELL(C.d)
+                                   const uint8_t* __restrict__ flags, MgLevel<T> C, int zc0) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z + zc0;
+    if (x >= C.d.nx || y >= C.d.ny) return;
     T acc = 0;
     for (int c = 0; c < 2; ++c)
         for (int b = 0; b < 2; ++b)
             for (int a = 0; a < 2; ++a) {
-                const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;
-                if (fx < 1 || fy < 1 || fz < 1 || fx >= g.nx - 1 || fy >= g.ny - 1 || fz >= g.nzl - 1) continue;
-                const int64_t i = gidx(g, fx, fy, fz);
+                const int fx = 2 * x + a, fy = 2 * y + b, fz = 2 * z + c;   // fz global
+                if (fx < 1 || fy < 1 || fz < 1 || fx >= g.nx - 1 || fy >= g.ny - 1 || fz >= g.gnz - 1) continue;
+                const int64_t i = gidx(g, fx, fy, fz - g.gz0);
                 if (!(flags[i] & FL_SELF_FLUID)) continue;
                 const T div = (u[i + 1] - u[i]) + (v[i + g.sy] - v[i]) + (w[i + g.sz] - w[i]);
                 acc += -div;
@@ -153,20 +163,22 @@ __global__ void k_mg_fine_residual(Grid g, const T* __restrict__ u, const T* __r
 }
 
 // faces between two Fluid cells take the gradient of the level-1 error of their cells' parents
+// (the local planes from zb on of one slab; the level-1 array spans the whole grid)
 template <typename T>
 __global__ void k_mg_apply(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w,
-                           const uint8_t* __restrict__ flags, MgLevel<T> C, T alpha) {
+                           const uint8_t* __restrict__ flags, MgLevel<T> C, T alpha, int zb) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int y = blockIdx.y * blockDim.y + threadIdx.y + 1;
-    const int z = blockIdx.z + 1;
+    const int z = blockIdx.z + zb;
     if (x >= g.nx - 1 || y >= g.ny - 1) return;
     const int64_t i = gidx(g, x, y, z);
     const uint32_t fl = flags[i];
     if (!(fl & FL_SELF_FLUID)) return;
-    const T eh = C.e[mgi(C.d, x / 2, y / 2, z / 2)];
-    if (fl & FL_XM) u[i] -= alpha * (eh - C.e[mgi(C.d, (x - 1) / 2, y / 2, z / 2)]);
-    if (fl & FL_YM) v[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, (y - 1) / 2, z / 2)]);
-    if (fl & FL_ZM) w[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, y / 2, (z - 1) / 2)]);
+    const int gz = z + g.gz0;
+    const T eh = C.e[mgi(C.d, x / 2, y / 2, gz / 2)];
+    if (fl & FL_XM) u[i] -= alpha * (eh - C.e[mgi(C.d, (x - 1) / 2, y / 2, gz / 2)]);
+    if (fl & FL_YM) v[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, (y - 1) / 2, gz / 2)]);
+    if (fl & FL_ZM) w[i] -= alpha * (eh - C.e[mgi(C.d, x / 2, y / 2, (gz - 1) / 2)]);
 }
 
 // The levels of at most 4096 cells in one workgroup: the sub-cycle below a level costs ~80 launches of a

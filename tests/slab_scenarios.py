@@ -93,8 +93,13 @@ def vortex_ring_deferred(fs, **kw):
     return vortex_ring(fs, check_every=-1, steps=8, **kw)
 
 
+def vortex_ring_multigrid(fs, **kw):
+    """The multigrid solver: every rank contributes its planes of level 1 and solves the coarse levels itself."""
+    return vortex_ring(fs, check_every=-1, steps=5, solver=1, **kw)
+
+
 SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, steps_maccormack, vortex_ring,
-                                     vortex_ring_deferred)}
+                                     vortex_ring_deferred, vortex_ring_multigrid)}
 
 
 def run(fs, name, rank=0, nranks=1, comm_id=None):

@@ -57,8 +57,41 @@ def test_multigrid_step_runs_the_benchmark_scene(fsamd):
 
 def test_multigrid_configuration_is_validated(fsamd):
     with pytest.raises(fsamd.FluidSimError):
-        fsamd.FluidSim3D(16, 16, 16, solver=1, local_slabs=2)
+        fsamd.FluidSim3D(16, 16, 18, solver=1, local_slabs=2)      # 9 + 9 planes: the second slab starts on an odd one
     with pytest.raises(fsamd.FluidSimError):
         fsamd.FluidSim3D(16, 16, 16, solver=1, ordering=fsamd.ORDER_LEXICOGRAPHIC)
     with pytest.raises(fsamd.FluidSimError):
         fsamd.FluidSim3D(16, 16, 16, solver=1, stop_mode=1)
+
+
+@pytest.mark.parametrize("kernel", [0, 1], ids=["one_pass", "two_pass"])
+@pytest.mark.parametrize("shape,slabs", [((28, 18, 24), 3), ((33, 20, 23), 3), ((40, 22, 32), 4), ((64, 40, 36), 2)])
+def test_multigrid_in_slabs_equals_single_domain(fsamd, shape, slabs, kernel):
+    # every slab contributes its planes of level 1, the coarse levels are solved on the whole grid: not a bit
+    # may differ from the single-domain cycle (random obstacles and StaticFluid cells inside)
+    nx, ny, nz = shape
+    _, a = make_pair(fsamd, nx, ny, nz, seed=6, scale=3.0, sweep_kernel=kernel)
+    _, b = make_pair(fsamd, nx, ny, nz, seed=6, scale=3.0, sweep_kernel=kernel, local_slabs=slabs)
+    for it in range(3):
+        a.mg_vcycle(); b.mg_vcycle()
+        for k in range(3):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), (it, k)
+    ra, rb = a.residual(), b.residual()
+    assert ra[1] == rb[1] and ra[0] == pytest.approx(rb[0], rel=1e-12)
+
+
+def test_multigrid_steps_in_slabs(fsamd):
+    n = 48
+    cfg = dict(step_mode=1, stop_mode=2, tol=1e-5, max_iters=200, solver=1, check_every=-1)
+    a = fsamd.FluidSim3D(n, n, n, **cfg)
+    b = fsamd.FluidSim3D(n, n, n, local_slabs=3, **cfg)
+    for g in (a, b):
+        g.sphere_influence(n / 10.0)
+        g.solid_sphere(5.0, 24.0, 30.0, 20.0)
+    for it in range(5):
+        for g in (a, b):
+            g.fill_sphere_influence(n / 10.0, it)
+            g.advance(1.0 / 30.0)
+        assert a.stats().sweeps_step == b.stats().sweeps_step
+        for k in range(4):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), (it, k)

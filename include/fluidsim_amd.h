@@ -116,7 +116,10 @@ enum {
                                 gradient form (levels of 2x2x2 blocks, red-black Gauss-Seidel on
                                 each, piecewise-constant transfer), 2 sweeps; the stopping rule is
                                 evaluated after every cycle and a cycle counts as 4 sweeps.  Same
-                                fixed point as the sweeps; red-black ordering, one slab only      */
+                                fixed point as the sweeps; red-black ordering.  With z-slabs every
+                                slab must start on an even plane; each rank then holds and solves
+                                the coarse levels of the whole grid (the fine level stays
+                                distributed), with the single-domain result bit for bit        */
 };
 
 /* step variants of fs3d_advance */

@@ -1040,7 +1040,10 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
             const T* qu = q_from_tmp ? (const T*)p.tmp[0] : F<T>(p, cv, 0);
             const T* qv = q_from_tmp ? (const T*)p.tmp[1] : F<T>(p, cv, 1);
             const T* qw = q_from_tmp ? (const T*)p.tmp[2] : F<T>(p, cv, 2);
-            const bool small = (size_t)p.n * sizeof(T) < ((size_t)1 << 32);   // byte offsets into a field fit 32 bits
+            // byte offsets into a field fit 32 bits (FSAMD_WIDE_OFFSETS=1 selects the 64-bit kernels regardless:
+            // the tests use it to run them on small grids)
+            static const bool force_wide = getenv("FSAMD_WIDE_OFFSETS") && getenv("FSAMD_WIDE_OFFSETS")[0] == '1';
+            const bool small = !force_wide && (size_t)p.n * sizeof(T) < ((size_t)1 << 32);
             const int a = p.H, b = p.H + p.own_planes();
             const int lo_end = slab && p.has_lo ? std::min(a + p.H, b) : a;
             const int hi_beg = slab && p.has_hi ? std::max(b - p.H, lo_end) : b;

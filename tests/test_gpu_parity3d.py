@@ -5,6 +5,8 @@ Bar: the working precision is the reference's (fp32) and every kernel performs t
 operations in the oracle's order, so fields must be IDENTICAL (np.array_equal); where a
 reduction order differs (parallel sums) the tolerance is stated in the test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -465,3 +467,17 @@ def test_slabs_with_overlapped_halo_traffic_at_a_size_where_kernels_overlap(fsam
             assert np.array_equal(a.get_field(k), b.get_field(k)), (it, k)
     da, db = a.diagnostics(), b.diagnostics()
     assert da.max_speed == db.max_speed and da.kinetic_energy == pytest.approx(db.kinetic_energy, rel=1e-12)
+
+
+def test_wide_offset_kernels_match_oracle():
+    # grids beyond 2^32 bytes per field (1024^3) take the advection kernels compiled with 64-bit offsets; a fresh
+    # process with FSAMD_WIDE_OFFSETS=1 runs the advection parity tests on them at small sizes
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSAMD_WIDE_OFFSETS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "--timeout", "120", "--timeout-method", "thread",
+                        os.path.join(root, "tests", "test_gpu_parity3d.py"), "-k",
+                        "semi_lagrange_bit_exact and 140 or reflection_step_random_state or local_slabs_bitwise"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -416,7 +416,7 @@ int launch_halfsweep(fs3d_sim* s, int colour) {
 template <typename Launch>
 int one_pass_driver(fs3d_sim* s, Launch launch) {
     if (s->nparts_global == 1) {
-        for (Part& p : s->parts) launch(p, 0, p.g.nzl, s->stream);
+        for (Part& p : s->parts) launch(p, 0, p.g.nzl, s->stream, 0);
         SIM_HIP(hipGetLastError());
         s->curv ^= 1;
         return FS_OK;
@@ -433,9 +433,13 @@ int one_pass_driver(fs3d_sim* s, Launch launch) {
         const int own_lo = p.H, own_hi = p.H + p.own_planes();
         const int lo_end = p.has_lo ? std::min(own_lo + 2, own_hi) : own_lo;
         const int hi_beg = p.has_hi ? std::max(own_hi - 2, lo_end) : own_hi;
-        if (lo_end > own_lo) launch(p, own_lo, lo_end, s->comm_stream);
-        if (own_hi > hi_beg) launch(p, hi_beg, own_hi, s->comm_stream);
-        if (hi_beg > lo_end) launch(p, lo_end, hi_beg, s->stream);
+        // (a slab with two interfaces: the planes next to both in one launch)
+        if (lo_end - own_lo == 2 && own_hi - hi_beg == 2 && hi_beg > lo_end) launch(p, own_lo, own_hi, s->comm_stream, 2);
+        else {
+            if (lo_end > own_lo) launch(p, own_lo, lo_end, s->comm_stream, 0);
+            if (own_hi > hi_beg) launch(p, hi_beg, own_hi, s->comm_stream, 0);
+        }
+        if (hi_beg > lo_end) launch(p, lo_end, hi_beg, s->stream, 0);
     }
     SIM_HIP(hipGetLastError());
     SIM_HIP(hipEventRecord(s->ev_b, s->comm_stream));
@@ -453,7 +457,7 @@ FusedRanges fused_ranges(const Part& p) {
     FusedRanges r;
     r.s1b = p.zb - (p.has_lo ? 1 : 0); r.s1e = p.ze;
     r.s0b = p.zb - (p.has_lo ? 2 : 0); r.s0e = p.ze + (p.has_hi ? 1 : 0);
-    r.z0 = 0; r.z1 = 0; r.zchunk = 1;
+    r.z0 = 0; r.z1 = 0; r.zchunk = 1; r.zlen = 1;
     return r;
 }
 
@@ -481,12 +485,16 @@ int launch_fused_sweep(fs3d_sim* s) {
     const T omega = (T)s->cfg.omega;
     const int cv = s->curv, ov = s->curv ^ 1;
     const int tiles = div_up(s->nx, TX) * div_up(s->ny, TY);
-    return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
+    return one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st, int ends) {
         FusedRanges r = fused_ranges<T>(p);
         r.z0 = z0; r.z1 = z1;
-        const int nchunks = pick_chunks(z1 - z0, tiles, 2 * s->num_cus);
-        r.zchunk = div_up(z1 - z0, nchunks);
-        dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), div_up(z1 - z0, r.zchunk));
+        if (ends > 0) {   // two workgroups along z: the first and the last `ends` planes of [z0, z1)
+            r.zchunk = z1 - ends - z0; r.zlen = ends;
+        } else {
+            const int nchunks = pick_chunks(z1 - z0, tiles, 2 * s->num_cus);
+            r.zchunk = r.zlen = div_up(z1 - z0, nchunks);
+        }
+        dim3 b(256, 1, 1), g(div_up(s->nx, TX), div_up(s->ny, TY), ends > 0 ? 2 : div_up(z1 - z0, r.zchunk));
         hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2),
                            F<T>(p, ov, 0), F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, omega, r);
     });
@@ -498,7 +506,7 @@ int launch_fused_sweep(fs3d_sim* s) {
 // provide about one workgroup per CU.
 // One launch of the rows kernel over `ntx` tiles of a row starting at column xbase (see the kernel for xedges).
 template <typename T, int NSEG, int CP>
-int launch_rows_tiles(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int ntx, int xbase, int xedges) {
+int launch_rows_tiles(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int ends, int ntx, int xbase, int xedges) {
     using C = RowsCfg<T, NSEG, CP>;
     auto kern = k_rb_rows<T, NSEG, CP>;
     SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
@@ -509,9 +517,15 @@ int launch_rows_tiles(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int 
     r.z0 = z0; r.z1 = z1;
     // the narrow variants fit 64 registers: two workgroups of 16 waves share a CU
     constexpr int per_cu = NSEG * CP * sizeof(T) <= 8 ? 2 : 1;
-    const int nchunks = pick_chunks(z1 - z0, ntx * nty, per_cu * s->num_cus);
-    r.zchunk = div_up(z1 - z0, nchunks);
-    dim3 b(64, rows, 1), g(ntx * nty * div_up(z1 - z0, r.zchunk), 1, 1);
+    int zgroups;
+    if (ends > 0) {   // two workgroups along z: the first and the last `ends` planes of [z0, z1)
+        r.zchunk = z1 - ends - z0; r.zlen = ends; zgroups = 2;
+    } else {
+        const int nchunks = pick_chunks(z1 - z0, ntx * nty, per_cu * s->num_cus);
+        r.zchunk = r.zlen = div_up(z1 - z0, nchunks);
+        zgroups = div_up(z1 - z0, r.zchunk);
+    }
+    dim3 b(64, rows, 1), g(ntx * nty * zgroups, 1, 1);
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
                        F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, r, ntx, nty, rows, xbase, xedges);
     return FS_OK;
@@ -532,12 +546,12 @@ int launch_rows_sweep(fs3d_sim* s) {
     const bool split = ntx >= 2 && C::W > 128 && last_cols <= C::W / 2;
     int rc = FS_OK;
     auto keep = [&](int r) { if (rc == FS_OK) rc = r; };
-    const int drc = one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st) {
-        if (!split) { keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ntx, 0, 3)); return; }
-        keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ntx - 1, 0, 1));
-        if (last_cols <= 128) keep(launch_rows_tiles<T, 1, 1>(s, p, z0, z1, st, 1, last_origin, 2));
-        else if (sizeof(T) == 4 && s->nx % 4 == 0) keep(launch_rows_tiles<T, 1, 2>(s, p, z0, z1, st, 1, last_origin, 2));
-        else keep(launch_rows_tiles<T, 2, 1>(s, p, z0, z1, st, 1, last_origin, 2));
+    const int drc = one_pass_driver(s, [&](Part& p, int z0, int z1, hipStream_t st, int ends) {
+        if (!split) { keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ends, ntx, 0, 3)); return; }
+        keep(launch_rows_tiles<T, NSEG, CP>(s, p, z0, z1, st, ends, ntx - 1, 0, 1));
+        if (last_cols <= 128) keep(launch_rows_tiles<T, 1, 1>(s, p, z0, z1, st, ends, 1, last_origin, 2));
+        else if (sizeof(T) == 4 && s->nx % 4 == 0) keep(launch_rows_tiles<T, 1, 2>(s, p, z0, z1, st, ends, 1, last_origin, 2));
+        else keep(launch_rows_tiles<T, 2, 1>(s, p, z0, z1, st, ends, 1, last_origin, 2));
     });
     return rc != FS_OK ? rc : drc;
 }

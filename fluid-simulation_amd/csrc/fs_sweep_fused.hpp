@@ -43,7 +43,9 @@ struct FusedRanges {
     int s0b, s0e;   // local planes the first colour visits
     int s1b, s1e;   // local planes the second colour visits
     int z0, z1;     // local planes this launch stores (the other planes of the output are left alone)
-    int zchunk;     // planes stored per workgroup along z
+    int zchunk;     // distance along z between the first planes of consecutive workgroups
+    int zlen;       // planes stored per workgroup (= zchunk, except where one launch serves two separate
+                    // ranges: the planes next to a slab's lower and upper interface)
 };
 
 template <typename T, int TX, int TY>
@@ -60,7 +62,7 @@ k_rb_fused(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int c0 = r.z0 + blockIdx.z * r.zchunk, c1 = min(c0 + r.zchunk, r.z1);   // planes this workgroup stores
+    const int c0 = r.z0 + blockIdx.z * r.zchunk, c1 = min(c0 + r.zlen, r.z1);   // planes this workgroup stores
     // a stored plane needs the second colour on itself and the plane below, and the first colour one
     // plane beyond that on either side
     const int s1b = max(r.s1b, c0 - 1), s1e = min(r.s1e, c1);

@@ -83,7 +83,7 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
     const int cy_lo = by == 0 ? 0 : yr0 + 2, cy_hi = by == nty - 1 ? g.ny : yr0 + rows - 2;
     const bool row_core = y >= cy_lo && y < cy_hi;
 
-    const int c0 = r.z0 + bz * r.zchunk, c1 = min(c0 + r.zchunk, r.z1);
+    const int c0 = r.z0 + bz * r.zchunk, c1 = min(c0 + r.zlen, r.z1);
     const int s1b = max(r.s1b, c0 - 1), s1e = min(r.s1e, c1);
     const int s0b = max(r.s0b, c0 - 2), s0e = min(r.s0e, c1 + 1);
     const int lb = max(0, c0 - 2), le = min(g.nzl, c1 + 2);

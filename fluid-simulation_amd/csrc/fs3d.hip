@@ -990,7 +990,7 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
 // generation's velocity into the other generation, then swaps generations.
 template <typename T, typename OFF, bool SLAB>
 int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, int cv, int ov, int cd, int od, T t_step,
-                  int density_mode, bool copy_to_tmp, bool reflect, bool with_res, int zb, int ze) {
+                  int density_mode, bool copy_to_tmp, bool reflect, bool with_res, int zb, int ze, int ends = 0) {
     if (ze <= zb) return FS_OK;
     T* c0 = copy_to_tmp ? (T*)p.tmp[0] : nullptr;
     T* c1 = copy_to_tmp ? (T*)p.tmp[1] : nullptr;
@@ -998,6 +998,10 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
     const T *U = F<T>(p, cv, 0), *V = F<T>(p, cv, 1), *W = F<T>(p, cv, 2);
     if (s->cfg.advect_kernel == FS_ADVECT_DIRECT) {
         if (with_res) return set_err(s, FS_ESTATE, "only the staged advection kernel evaluates the residual");
+        if (ends > 0) {   // one thread per location and no march along z: two plain launches
+            FS_TRY((launch_advect<T, OFF, SLAB>(s, p, qu, qv, qw, cv, ov, cd, od, t_step, density_mode, copy_to_tmp, reflect, false, zb, zb + ends)));
+            return launch_advect<T, OFF, SLAB>(s, p, qu, qv, qw, cv, ov, cd, od, t_step, density_mode, copy_to_tmp, reflect, false, ze - ends, ze);
+        }
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), ze - zb);
         hipLaunchKernelGGL((k_advect<T, OFF, SLAB>), g, b, 0, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0),
                            F<T>(p, ov, 1), F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb,
@@ -1009,9 +1013,15 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         const int tiles = div_up(s->nx, 64) * div_up(s->ny, 8);
         // workgroups a CU holds at once: limited by LDS (160 KiB) and, at 72 registers, to 3 x 8 waves
         const int per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / lds)));
-        const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus);
-        const int zchunk = div_up(ze - zb, nchunks);
-        dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), div_up(ze - zb, zchunk));
+        int zchunk, zlen, zgroups;
+        if (ends > 0) {   // two workgroups along z: the first and the last `ends` planes of [zb, ze)
+            zchunk = ze - ends - zb; zlen = ends; zgroups = 2;
+        } else {
+            const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus);
+            zchunk = zlen = div_up(ze - zb, nchunks);
+            zgroups = div_up(ze - zb, zchunk);
+        }
+        dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), zgroups);
         double* res_part = nullptr;
         if (with_res) {   // the launches of one advection write their partials one after the other
             const size_t blocks = (size_t)g.x * g.y * g.z;
@@ -1026,7 +1036,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
             p.adv_blocks += (int)blocks;
         }
         hipLaunchKernelGGL(kern, g, b, lds, s->stream, p.g, qu, qv, qw, F<T>(p, cd, 3), U, V, W, F<T>(p, ov, 0), F<T>(p, ov, 1),
-                           F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, s->doob,
+                           F<T>(p, ov, 2), F<T>(p, od, 3), c0, c1, c2, p.flags, t_step, density_mode, zb, ze, zchunk, zlen, s->doob,
                            res_part);
         return FS_OK;
     };
@@ -1061,13 +1071,16 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
             const int a = p.H, b = p.H + p.own_planes();
             const int lo_end = slab && p.has_lo ? std::min(a + p.H, b) : a;
             const int hi_beg = slab && p.has_hi ? std::max(b - p.H, lo_end) : b;
-            const int ranges[3][2] = {{a, lo_end}, {hi_beg, b}, {lo_end, hi_beg}};
+            // pass 0: the planes next to the interfaces, both ends in one launch where the slab has two of the
+            // same depth; pass 1: the rest
+            const bool both = lo_end - a == p.H && b - hi_beg == p.H && hi_beg > lo_end;
+            const int ranges[3][3] = {{a, both ? b : lo_end, both ? p.H : 0}, {hi_beg, both ? hi_beg : b, 0}, {lo_end, hi_beg, 0}};
             for (int r = pass == 0 ? 0 : 2; r < (pass == 0 ? 2 : 3); ++r) {
-                const int zb = ranges[r][0], ze = ranges[r][1];
-                if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
-                else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
-                else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
-                else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze)));
+                const int zb = ranges[r][0], ze = ranges[r][1], ends = ranges[r][2];
+                if (small && slab) FS_TRY((launch_advect<T, uint32_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze, ends)));
+                else if (small) FS_TRY((launch_advect<T, uint32_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze, ends)));
+                else if (slab) FS_TRY((launch_advect<T, int64_t, true>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze, ends)));
+                else FS_TRY((launch_advect<T, int64_t, false>(s, p, qu, qv, qw, cv, ov, cd, od, (T)t_step, density_mode, copy_to_tmp, reflect, res_sum != nullptr, zb, ze, ends)));
             }
         }
         SIM_HIP(hipGetLastError());

@@ -44,7 +44,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
                const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
                T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od, T* __restrict__ cu,
                T* __restrict__ cv, T* __restrict__ cw, const uint8_t* __restrict__ flags, T t_step, int density_mode,
-               int zb, int ze, int zchunk, int* __restrict__ oob_flag, double* __restrict__ res_part) {
+               int zb, int ze, int zchunk, int zlen, int* __restrict__ oob_flag, double* __restrict__ res_part) {
     using C = AdvTile<T, SEP>;
     constexpr int R = C::R, WX = C::WX, PS = C::PS, NPL = C::NPL;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -52,7 +52,9 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
 
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * C::TX + tx;
     const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY;
-    const int c0 = zb + blockIdx.z * zchunk, c1 = min(c0 + zchunk, ze);
+    // a workgroup's planes: zlen of them every zchunk planes (zlen = zchunk, except where one launch serves the
+    // planes next to a slab's lower and upper interface)
+    const int c0 = zb + blockIdx.z * zchunk, c1 = min(c0 + zlen, ze);
     const OFF sy = (OFF)g.nx * (OFF)sizeof(T), sz = (OFF)g.nx * (OFF)g.ny * (OFF)sizeof(T);
     const T* src[7] = {qu, qv, qw, qd, U, V, W};
 

@@ -92,6 +92,8 @@ struct fs3d_sim {
     int* doob = nullptr;         // device flag: a backtrace left the slab's halo
     int* hoob = nullptr;
     ncclComm_t comm = nullptr;
+    ncclComm_t comm_red = nullptr;   // the communicator of the scalar all-reduces: a copy of `comm` where the library
+                                     // can make one (the reductions then need not queue behind the halo traffic), else `comm`
     Rccl* rccl = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     fs3d_stats stats{};
@@ -614,14 +616,16 @@ int oob_status(fs3d_sim* s) {
 // Queues, on the main stream, the combination of the per-part pairs (across ranks too) and their copy to
 // the host mirror.
 int queue_reduction(fs3d_sim* s, bool want_max) {
-    FS_TRY(join_halos(s));   // one stream at a time on the communicator
+    // one stream at a time on a communicator: with a communicator of their own the reductions run beside
+    // the halo traffic of the other stream (every rank issues the two in the same order)
+    if (s->nranks > 1 && s->comm_red == s->comm) FS_TRY(join_halos(s));
     double* comb = s->dres + 2 * s->nlocal;
     hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
     SIM_HIP(hipGetLastError());
     if (s->nranks > 1) {
-        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm, s->stream), "ncclAllReduce"));
+        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm_red, s->stream), "ncclAllReduce"));
         if (want_max)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
-            FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce"));
+            FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm_red, s->stream), "ncclAllReduce"));
     }
     SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     return FS_OK;
@@ -1535,6 +1539,11 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
         static_assert(sizeof(uid) == FS_COMM_ID_BYTES, "unique id size");
         memcpy(&uid, id, sizeof uid);
         FS_TRY(nccl_check(s, s->rccl->CommInitRank(&s->comm, nranks, uid, rank), "ncclCommInitRank"));
+        s->comm_red = s->comm;
+        if (s->rccl->CommSplit && !(getenv("FSAMD_ONE_COMMUNICATOR") && getenv("FSAMD_ONE_COMMUNICATOR")[0] == '1')) {
+            ncclComm_t copy = nullptr;   // same ranks, same order; every rank takes part (collective call)
+            if (s->rccl->CommSplit(s->comm, 0, rank, &copy, nullptr) == ncclSuccess && copy) s->comm_red = copy;
+        }
     }
     FS_TRY(alloc_parts(s));
     FS_TRY(zero_fields(s));
@@ -1618,6 +1627,19 @@ int fsamd_comm_selftest(int device) {
         ok = ok && R->Send(d, n * sizeof(double), ncclUint8, 0, comm, st) == ncclSuccess;
         ok = ok && R->Recv(d + n, n * sizeof(double), ncclUint8, 0, comm, st) == ncclSuccess;
         ok = ok && R->GroupEnd() == ncclSuccess;
+        // the copy of the communicator that the scalar reductions use, where the library offers the call: an
+        // all-reduce on it, on another stream, while the first communicator is busy
+        if (ok && R->CommSplit) {
+            ncclComm_t copy = nullptr;
+            hipStream_t st2 = nullptr;
+            if (R->CommSplit(comm, 0, 0, &copy, nullptr) == ncclSuccess && copy) {
+                ok = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess;
+                ok = ok && R->AllReduce(d + 2 * n, d + 2 * n, 1, ncclDouble, ncclSum, copy, st2) == ncclSuccess;
+                ok = ok && hipStreamSynchronize(st2) == hipSuccess;
+                if (st2) (void)hipStreamDestroy(st2);
+                (void)R->CommDestroy(copy);
+            }
+        }
         if (!ok) rc = FS_ECOMM;
     }
     if (rc == FS_OK && (hipStreamSynchronize(st) != hipSuccess ||
@@ -1653,6 +1675,7 @@ void fs3d_destroy(fs3d_sim* s) {
     DeviceGuard guard(s->device);
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm_red && s->comm_red != s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm_red);
     if (s->comm && s->rccl) (void)s->rccl->CommDestroy(s->comm);
     free_parts(s);
     (void)hipFree(s->dres);

@@ -25,6 +25,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommSplit) CommSplit = nullptr;   // optional: absent from old builds
 
     // Returns the process-wide binding or nullptr (err says why).
     static Rccl* get(std::string& err) {
@@ -63,6 +64,7 @@ struct Rccl {
                 inst.GroupEnd = (decltype(inst.GroupEnd))sym("ncclGroupEnd");
                 inst.AllReduce = (decltype(inst.AllReduce))sym("ncclAllReduce");
                 inst.GetErrorString = (decltype(inst.GetErrorString))sym("ncclGetErrorString");
+                if (ok) inst.CommSplit = (decltype(inst.CommSplit))dlsym(inst.handle, "ncclCommSplit");
                 if (!ok) { dlclose(inst.handle); inst.handle = nullptr; }
             }
         }

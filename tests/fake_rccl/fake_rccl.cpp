@@ -1,4 +1,4 @@
-// Test stand-in for librccl: the nine entry points the fluid library binds with dlopen, carried over POSIX
+// Test stand-in for librccl: the entry points the fluid library binds with dlopen (nine, and ncclCommSplit), over POSIX
 // shared memory between processes that may all sit on ONE GPU.
 //
 // RCCL refuses two ranks of a communicator on the same device, so the rank-to-rank side of the z-slab code (who
@@ -46,6 +46,11 @@ struct Shared {
     std::atomic<int> bar_gen;
     std::atomic<int> failed;
     double red[kMaxRanks][kMaxRed];
+    // a second set of barrier and reduction slots for the communicator ncclCommSplit hands out (the library
+    // uses it for all-reduces only, concurrently with send/receive traffic on the first)
+    std::atomic<int> bar2_count;
+    std::atomic<int> bar2_gen;
+    double red2[kMaxRanks][kMaxRed];
     Mailbox box[kMaxRanks * kMaxRanks];   // [src * kMaxRanks + dst]
 };
 
@@ -69,6 +74,7 @@ thread_local std::vector<std::pair<struct ncclComm*, Op>> group_ops;
 struct ncclComm {
     Shared* sh = nullptr;
     int rank = 0, nranks = 1;
+    bool second = false;   // made by ncclCommSplit
     char name[64];
 };
 
@@ -76,14 +82,16 @@ namespace {
 
 ncclResult_t barrier(ncclComm* c) {
     Shared* sh = c->sh;
-    const int gen = sh->bar_gen.load(std::memory_order_acquire);
-    if (sh->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == c->nranks) {
-        sh->bar_count.store(0, std::memory_order_relaxed);
-        sh->bar_gen.fetch_add(1, std::memory_order_acq_rel);
+    std::atomic<int>& count = c->second ? sh->bar2_count : sh->bar_count;
+    std::atomic<int>& bgen = c->second ? sh->bar2_gen : sh->bar_gen;
+    const int gen = bgen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == c->nranks) {
+        count.store(0, std::memory_order_relaxed);
+        bgen.fetch_add(1, std::memory_order_acq_rel);
         return ncclSuccess;
     }
     const double t0 = now();
-    while (sh->bar_gen.load(std::memory_order_acquire) == gen) {
+    while (bgen.load(std::memory_order_acquire) == gen) {
         if (sh->failed.load() || now() - t0 > kDeadline) { sh->failed.store(1); return ncclSystemError; }
         usleep(20);
     }
@@ -200,8 +208,19 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclSuccess;
-    munmap(c->sh, sizeof(Shared));
+    if (!c->second) munmap(c->sh, sizeof(Shared));   // a split communicator borrows its parent's mapping
     delete c;
+    return ncclSuccess;
+}
+
+// Only what the library asks for: one colour, ranks in their order, all-reduces on the new communicator.  It must
+// be destroyed before its parent.
+ncclResult_t ncclCommSplit(ncclComm_t c, int color, int key, ncclComm_t* out, ncclConfig_t* config) {
+    (void)config;
+    if (!c || !out || c->second || color != 0 || key != c->rank) return ncclInvalidArgument;
+    ncclComm* n = new ncclComm(*c);
+    n->second = true;
+    *out = n;
     return ncclSuccess;
 }
 
@@ -236,15 +255,16 @@ ncclResult_t ncclAllReduce(const void* in, void* out, size_t count, ncclDataType
     if (!c || dt != ncclFloat64 || count > (size_t)kMaxRed || (op != ncclSum && op != ncclMax && op != ncclMin))
         return ncclInvalidArgument;   // the library reduces fp64 scalars only
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
-    double* mine = c->sh->red[c->rank];
+    double (*red)[kMaxRed] = c->second ? c->sh->red2 : c->sh->red;
+    double* mine = red[c->rank];
     if (hipMemcpy(mine, in, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     ncclResult_t r = barrier(c);
     if (r != ncclSuccess) return r;
     double acc[kMaxRed];
     for (size_t i = 0; i < count; ++i) {
-        double a = c->sh->red[0][i];
+        double a = red[0][i];
         for (int k = 1; k < c->nranks; ++k) {   // rank order: every rank forms the same sum
-            const double b = c->sh->red[k][i];
+            const double b = red[k][i];
             a = op == ncclSum ? a + b : op == ncclMax ? (b > a ? b : a) : (b < a ? b : a);
         }
         acc[i] = a;

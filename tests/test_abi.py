@@ -69,5 +69,5 @@ def test_rccl_stand_in_exports_what_the_library_binds():
         pytest.skip("tests/fake_rccl not built")
     lib = ctypes.CDLL(path)
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart",
-                 "ncclGroupEnd", "ncclAllReduce", "ncclGetErrorString"):
+                 "ncclGroupEnd", "ncclAllReduce", "ncclGetErrorString", "ncclCommSplit"):
         assert hasattr(lib, name), name

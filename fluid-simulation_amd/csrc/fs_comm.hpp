@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 namespace fsamd {
@@ -32,6 +33,8 @@ struct Rccl {
         static Rccl inst;
         static bool tried = false;
         static std::string failure;
+        static std::mutex mu;   // handles may be created from several host threads
+        std::lock_guard<std::mutex> lock(mu);
         if (!tried) {
             tried = true;
             // FSAMD_RCCL_LIBRARY names the library to bind instead of the system's RCCL (a site build, or the

@@ -85,6 +85,8 @@ struct fs3d_sim {
     int rank = 0, nranks = 1, nlocal = 1, nparts_global = 1;
     std::vector<Part> parts;
     int curv = 0, curd = 0;      // generation holding the current velocity (u,v,w) / density
+    int tilde_gen = -1;          // inside a reflection step: the generation whose velocity arrays still hold the
+                                 // unprojected half-step field (else it is in the scratch fields, or not needed)
     bool cells_dirty = true;
     int halo_dirty = 7;          // halo planes that lag their owners: bit 0 velocity, bit 1 density, bit 2 scratch velocity
     double* dres = nullptr;      // 2 doubles per local part + 2 combined
@@ -415,8 +417,22 @@ int launch_halfsweep(fs3d_sim* s, int colour) {
 // of exchanging per colour.  With more than one slab the two owned planes next to each interface are
 // produced on the second stream, followed there by their exchange, while the main stream sweeps the
 // interior of the slab; the main stream picks the halos up before anything reads them.
+// The reflection needs the unprojected half-step velocity after the projection that follows it.  The first
+// half advection leaves it in the generation it writes; a one-pass sweep reads one generation and writes the
+// other, so the field survives the first sweep of that projection untouched.  Whoever is about to overwrite
+// that generation (a second sweep, or the second half advection) first trades its velocity arrays for the
+// scratch arrays: the field is then "in the scratch fields" without a copy, halo planes included.
+void tilde_to_tmp(fs3d_sim* s) {
+    if (s->tilde_gen < 0) return;
+    for (Part& p : s->parts)
+        for (int k = 0; k < 3; ++k) std::swap(p.f[s->tilde_gen][k], p.tmp[k]);
+    s->halo_dirty &= ~HALO_TMP;   // its halo planes came with the exchange that followed the advection
+    s->tilde_gen = -1;
+}
+
 template <typename Launch>
 int one_pass_driver(fs3d_sim* s, Launch launch) {
+    if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
     if (s->nparts_global == 1) {
         for (Part& p : s->parts) launch(p, 0, p.g.nzl, s->stream, 0);
         SIM_HIP(hipGetLastError());
@@ -1217,6 +1233,7 @@ int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projec
     s->curv ^= 1;
     s->curd ^= 1;
     s->halo_dirty |= HALO_ALL;
+    if (slot == 0) s->tilde_gen = -1;   // the dropped generation held ut
     s->spec_fails[slot] = std::min(s->spec_fails[slot] + 1, 3);
     s->spec_backoff[slot] = 1 << s->spec_fails[slot];
     ++s->stats.redone;
@@ -1228,6 +1245,7 @@ template <typename T>
 int step(fs3d_sim* s, double dt) {
     s->stats.sweeps_step = 0;
     s->stats.evaluations_step = 0;
+    s->tilde_gen = -1;
     s->resid_dt = dt > 0 ? dt : 1.0;
     SIM_HIP(hipEventRecord(s->ev[0], s->stream));
     if (s->cfg.buoyancy != 0.0) FS_TRY(buoyancy<T>(s, dt));
@@ -1245,14 +1263,21 @@ int step(fs3d_sim* s, double dt) {
         // Advection-reflection, phase-shifted to the reference's convention of projecting first and
         // leaving the advected field for the next step to project:
         //   u0 = P(state); ut = A(u0; u0, dt/2); uh = P(ut); ur = 2 uh - ut; state = A(ur; uh, dt/2)
+        // ut is needed again after the second projection.  Where that projection sweeps out of place and the
+        // staged kernel does the second advection, ut stays in the generation the first advection writes and
+        // reaches the scratch fields by a trade of arrays (tilde_to_tmp); else the advection writes it twice.
+        const bool keep = !mac && s->cfg.advect_kernel == FS_ADVECT_TILED && s->cfg.ordering == FS_ORDER_RED_BLACK &&
+                          s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
         FS_TRY((project_then_advect<T>(s, 0, mac, nullptr, [&](double* res) -> int {
-            FS_TRY(advect<T>(s, 0.5 * dt, false, 0, !mac, false, res));   // ut goes to the scratch fields as well
+            FS_TRY(advect<T>(s, 0.5 * dt, false, 0, !mac && !keep, false, res));
+            if (keep) s->tilde_gen = s->curv;
             if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, false, true));
             return (int)FS_OK;
         })));
         FS_TRY((project_then_advect<T>(s, 1, mac, s->ev[1], [&](double* res) -> int {
             if (s->cfg.advect_kernel == FS_ADVECT_TILED && !mac) {
                 // the staged kernel forms ur while it loads ut and uh: no reflection pass
+                tilde_to_tmp(s);   // (after a single sweep ut is still in the generation this advection writes)
                 return advect<T>(s, 0.5 * dt, true, 0, false, true, res);
             }
             FS_TRY(prepare(s, HALO_VEL | HALO_TMP));   // the reflection runs over halo planes too
@@ -1695,6 +1720,7 @@ int fs3d_reset(fs3d_sim* s) {
     FS_TRY(init_cells(s));
     s->curv = 0;
     s->curd = 0;
+    s->tilde_gen = -1;
     s->sweep_hint[0] = s->sweep_hint[1] = 1;
     s->sweep_hint_prev[0] = s->sweep_hint_prev[1] = 0;
     for (int k = 0; k < 2; ++k) s->spec_backoff[k] = s->spec_fails[k] = s->mg_backoff[k] = s->mg_fails[k] = 0;

@@ -1,8 +1,11 @@
 """One rank of a multi-process z-slab run (started by tests/test_gpu_slab_ranks.py, one process per rank, all
-on GPU 0 through the shared-memory stand-in for RCCL).  Runs the scenario named on the command line, gathers
-the global fields on rank 0 and writes them to an .npz for the parent to compare with its single-domain run."""
+on GPU 0 through the shared-memory stand-in for RCCL).  Runs the scenario named on the command line and writes
+its owned planes and scalars to <out>.rank<r>.npz for the parent to assemble and compare with its single-domain
+run.  The communicator id travels through a file: no torch in these processes (the torch.distributed control
+plane has its own tests, and the benchmark's launch line is rehearsed separately)."""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,26 +15,23 @@ import numpy as np
 
 def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import fsamd_loader
     fs = fsamd_loader.load()
-    from fluid_simulation_amd import dist as fd
     from tests import slab_scenarios as sc
-    rank, world = fd.init_control_plane("gloo")
-    comm_id = fd.broadcast_bytes(fs.comm_unique_id() if rank == 0 else None)
-    record = sc.run(fs, scenario, rank=rank, nranks=world, comm_id=comm_id)
-    gathered = {}
-    for key, val in record.items():
-        if isinstance(val, np.ndarray) and val.ndim == 3:
-            g = fd.gather_planes(val)
-            if rank == 0:
-                gathered[key] = g
-        elif rank == 0:
-            gathered[key] = np.asarray(val)
+    id_path = out_path + ".id"
     if rank == 0:
-        np.savez(out_path, **gathered)
-    import torch.distributed as dist
-    dist.barrier()
-    dist.destroy_process_group()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(fs.comm_unique_id())
+        os.replace(id_path + ".tmp", id_path)
+    deadline = time.time() + 120
+    while not os.path.exists(id_path):
+        if time.time() > deadline:
+            raise SystemExit("no communicator id from rank 0")
+        time.sleep(0.01)
+    comm_id = open(id_path, "rb").read()
+    record = sc.run(fs, scenario, rank=rank, nranks=world, comm_id=comm_id)
+    np.savez(f"{out_path}.rank{rank}.npz", **{k: np.asarray(v) for k, v in record.items()})
     print(f"rank {rank} done", flush=True)
 
 

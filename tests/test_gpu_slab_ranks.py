@@ -1,9 +1,9 @@
 """Several ranks of the z-slab path as separate processes on ONE GPU.
 
 RCCL does not accept two ranks of a communicator on one device, so the processes bind the shared-memory
-stand-in of tests/fake_rccl through FSAMD_RCCL_LIBRARY; everything above the nine RCCL entry points (which planes
-go to which neighbour on which stream, the all-reduced stopping scalars, the torch.distributed control plane, the
-benchmark's launch line) is the product code, unchanged.  Red-black order is partition independent: the gathered
+stand-in of tests/fake_rccl through FSAMD_RCCL_LIBRARY; everything above the RCCL entry points (which planes go to
+which neighbour on which stream, the all-reduced stopping scalars, and, in the last test, the torch.distributed
+control plane and the benchmark's launch line) is the product code, unchanged.  Red-black order is partition independent: the gathered
 fields must equal the single-domain run bit for bit."""
 import json
 import os
@@ -56,17 +56,22 @@ def run_ranks(argv, world, timeout=150):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("scenario", sorted(slab_scenarios.SCENARIOS))
 def test_ranks_equal_single_domain(fsamd, tmp_path, scenario, world):
-    out = str(tmp_path / "ranks.npz")
+    out = str(tmp_path / "ranks")
     run_ranks([os.path.join(ROOT, "tests", "ranks", "slab_rank_worker.py"), scenario, out], world)
-    got = np.load(out)
+    parts = [np.load(f"{out}.rank{r}.npz") for r in range(world)]
     want = slab_scenarios.run(fsamd, scenario)
-    assert sorted(got.files) == sorted(want)
+    assert sorted(parts[0].files) == sorted(want)
     for key, val in want.items():
         val = np.asarray(val)
-        if val.ndim == 3 or key.endswith("_sweeps") or key == "res_max":
-            assert np.array_equal(got[key], val), key
+        if val.ndim == 3:      # owned planes of every rank, one after the other
+            assert np.array_equal(np.concatenate([p[key] for p in parts], axis=0), val), key
+            continue
+        for p in parts[1:]:    # every rank holds the same scalars
+            assert np.array_equal(p[key], parts[0][key]), key
+        if key.endswith("_sweeps") or key == "res_max":
+            assert np.array_equal(parts[0][key], val), key
         else:   # sums reduced in a different order
-            assert np.allclose(got[key], val, rtol=1e-9, atol=0), key
+            assert np.allclose(parts[0][key], val, rtol=1e-9, atol=0), key
 
 
 def test_bench_launch_line_with_two_ranks(fsamd):

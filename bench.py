@@ -243,7 +243,7 @@ def main():
                 "sweeps_per_step": sweeps_per_step, "residual_passes_per_step": evals / a.steps,
                 "redone_advections": st.redone, "last_residual": st.metric,
                 "residual_norm": "sqrt(sum (div/dt)^2) / #interior cells, the norm of 3_fluid/FluidSim.cpp:25-43",
-                "device_ms_project": st.ms_project, "device_ms_advect": st.ms_advect,
+                "device_ms_until_last_projection": st.ms_project, "device_ms_last_advection": st.ms_advect,
             },
             "roofline": {
                 "bound": "hbm", "kernel": f"k_rb_rows<{'double' if a.dtype == 'f64' else 'float'}> (one-pass red-black sweep)",

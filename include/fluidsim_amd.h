@@ -156,8 +156,10 @@ typedef struct fs3d_stats {
     int32_t sweeps;          /* sweeps of the last projection                                    */
     int32_t sweeps_step;     /* sweeps of all projections of the last step                       */
     double metric;           /* last evaluated stopping metric (change or residual)              */
-    double ms_project;       /* device time of the last step's projections, milliseconds         */
-    double ms_advect;        /* device time of the last step's advections (+ reflection)         */
+    double ms_project;       /* device time of the last step up to the end of its last projection,
+                                milliseconds (in the reflection step the first half advection lies
+                                between the two projections and is included)                      */
+    double ms_advect;        /* device time of the last step's last advection (+ reflection)      */
     double ms_step;          /* device time of the whole last step                               */
     int32_t evaluations_step;/* passes over the velocity that evaluated the stopping metric in the last
                                 step (an evaluation folded into an advection is not a pass)         */

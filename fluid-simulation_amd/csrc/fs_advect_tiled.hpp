@@ -149,15 +149,15 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             // generic-address load per tap, which is served at a fraction of the LDS rate)
             const volatile T* r00 = at_byte(src[f], trace_base(g, tr));
             const volatile T* r10 = at_byte(src[f], trace_base(g, tr) + sy);
-            const volatile T* r01 = at_byte(src[f], trace_base(g, tr) + sz);
-            const volatile T* r11 = at_byte(src[f], trace_base(g, tr) + sz + sy);
+            const volatile T* r01 = at_byte(src[f], trace_base(g, tr) + tr.dz1);
+            const volatile T* r11 = at_byte(src[f], trace_base(g, tr) + tr.dz1 + sy);
             t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
             t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
             if (REFL && f < 3) {
                 const volatile T* c00 = at_byte(src[4 + f], trace_base(g, tr));
                 const volatile T* c10 = at_byte(src[4 + f], trace_base(g, tr) + sy);
-                const volatile T* c01 = at_byte(src[4 + f], trace_base(g, tr) + sz);
-                const volatile T* c11 = at_byte(src[4 + f], trace_base(g, tr) + sz + sy);
+                const volatile T* c01 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1);
+                const volatile T* c11 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1 + sy);
                 t.s[0] = (T)2 * c00[0] - t.s[0]; t.s[1] = (T)2 * c00[1] - t.s[1]; t.s[2] = (T)2 * c10[0] - t.s[2];
                 t.s[3] = (T)2 * c01[0] - t.s[3]; t.s[4] = (T)2 * c10[1] - t.s[4]; t.s[5] = (T)2 * c01[1] - t.s[5];
                 t.s[6] = (T)2 * c11[0] - t.s[6]; t.s[7] = (T)2 * c11[1] - t.s[7];

@@ -330,6 +330,8 @@ template <typename T>
 struct Trace {
     T fu, fv, fw;
     int64_t base;
+    int64_t dz1;    // elements from the plane of tap 0 to the plane of tap 3: one plane, or 0 where a slab holds
+                    // only one of the two planes (the other is then a tap the reference does not read)
     uint32_t ok;    // bit k: tap k (order of main.cpp:400-407) is read by the reference
     bool oob;
 };
@@ -359,8 +361,14 @@ __device__ __forceinline__ Trace<T> trace_prepare(const Grid& g, int x, int y, i
     tr.ok = (uint32_t)(x0 && y0 && z0) | ((uint32_t)(x1 && y0 && z0) << 1) | ((uint32_t)(x0 && y1 && z0) << 2) |
             ((uint32_t)(x0 && y0 && z1) << 3) | ((uint32_t)(x1 && y1 && z0) << 4) | ((uint32_t)(x1 && y0 && z1) << 5) |
             ((uint32_t)(x0 && y1 && z1) << 6) | ((uint32_t)(x1 && y1 && z1) << 7);
-    const int cx = min(max(ibx, 0), g.nx - 2), cy = min(max(iby, 0), g.ny - 2), cz = min(max(lzb, 0), g.nzl - 2);
-    tr.base = gidx(g, cx, cy, cz);
+    // x, y: clamping the base into [0, n-2] never moves a tap the reference reads (such a tap has both itself
+    // and its base in range).  z: the first and the last plane a slab holds can be read taps whose partner plane
+    // lies outside the slab (and is then the shell of the grid, which is not read), so the two tap planes are
+    // clamped one by one
+    const int cx = min(max(ibx, 0), g.nx - 2), cy = min(max(iby, 0), g.ny - 2);
+    const int cz0 = min(max(lzb, 0), g.nzl - 1), cz1 = min(max(lzb + 1, 0), g.nzl - 1);
+    tr.base = gidx(g, cx, cy, cz0);
+    tr.dz1 = (int64_t)(cz1 - cz0) * g.sz;
     return tr;
 }
 
@@ -370,8 +378,9 @@ template <typename T>
 __device__ __forceinline__ Taps<T> trace_gather(const Grid& g, const T* __restrict__ q, const Trace<T>& tr) {
     const T* b = q + tr.base;
     Taps<T> t;
-    t.s[0] = b[0]; t.s[1] = b[1]; t.s[2] = b[g.sy]; t.s[3] = b[g.sz];
-    t.s[4] = b[g.sy + 1]; t.s[5] = b[g.sz + 1]; t.s[6] = b[g.sz + g.sy]; t.s[7] = b[g.sz + g.sy + 1];
+    const T* b1 = b + tr.dz1;
+    t.s[0] = b[0]; t.s[1] = b[1]; t.s[2] = b[g.sy]; t.s[3] = b1[0];
+    t.s[4] = b[g.sy + 1]; t.s[5] = b1[1]; t.s[6] = b1[g.sy]; t.s[7] = b1[g.sy + 1];
     return t;
 }
 
@@ -413,6 +422,7 @@ template <typename T, typename OFF>
 struct FastTrace {
     T x0, x1, y0, y1, z0, z1;   // (1-fu), fu, (1-fv), fv, (1-fw), fw, or 0 where the tap is not read
     int cx, cy, cz;             // tap 0, clamped into the array (cz is a local plane)
+    OFF dz1;                    // bytes from the plane of tap 0 to the plane of tap 3 (see Trace::dz1)
     bool oob, far;
 };
 
@@ -456,7 +466,15 @@ __device__ __forceinline__ FastTrace<T, OFF> fast_prepare(const Grid& g, int x, 
         fu = fu / ((bx + one) - bx); fv = fv / ((by + one) - by); fw = fw / ((bz + one) - bz);
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
     }
-    tr.cx = min(max(ibx, 0), g.nx - 2); tr.cy = min(max(iby, 0), g.ny - 2); tr.cz = min(max(lzb, 0), g.nzl - 2);
+    tr.cx = min(max(ibx, 0), g.nx - 2); tr.cy = min(max(iby, 0), g.ny - 2);
+    const OFF plane = (OFF)g.nx * (OFF)g.ny * (OFF)sizeof(T);
+    if (SLAB) {   // the two tap planes clamped one by one, see trace_prepare
+        tr.cz = min(max(lzb, 0), g.nzl - 1);
+        tr.dz1 = (OFF)(min(max(lzb + 1, 0), g.nzl - 1) - tr.cz) * plane;
+    } else {
+        tr.cz = min(max(lzb, 0), g.nzl - 2);
+        tr.dz1 = plane;
+    }
     return tr;
 }
 
@@ -520,7 +538,8 @@ __device__ __forceinline__ T fast_finish(const FastTrace<T, OFF>& tr, Taps<T>& t
 
 template <typename T, typename OFF>
 __device__ __forceinline__ T fast_sample(const Grid& g, const T* __restrict__ q, const FastTrace<T, OFF>& tr, OFF sy, OFF sz) {
-    Taps<T> t = fast_gather<T, OFF>(q, trace_base(g, tr), sy, sz);
+    (void)sz;
+    Taps<T> t = fast_gather<T, OFF>(q, trace_base(g, tr), sy, tr.dz1);
     return fast_finish(tr, t);
 }
 

@@ -481,3 +481,29 @@ def test_wide_offset_kernels_match_oracle():
                        env=env, cwd=root, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_slab_whose_outer_halo_plane_is_the_last_interior_plane(fsamd):
+    # 23 planes in 6 slabs: the fifth slab's upper halo ends on plane 21, the last interior plane of the grid.  A
+    # backtrace from that slab that lands between planes 21 and 22 reads plane 21 (held) and the shell plane 22
+    # (not held, not read): the held plane must not be displaced when the base of the pair is clamped into the
+    # slab.  (Found by scripts/fuzz_slabs.py; same for a first slab of three planes, mirrored.)
+    nx, ny, nz = 91, 34, 23
+    cfg = dict(stop_mode=0, max_iters=11)
+    o, a = make_pair(fsamd, nx, ny, nz, seed=800870221, scale=40.0, **cfg)
+    _, b = make_pair(fsamd, nx, ny, nz, seed=800870221, scale=40.0, local_slabs=6, **cfg)
+    for flip in (False, True):
+        if flip:   # the mirrored case: the same fields upside down, w negated
+            for g in (a, b):
+                f = [g.get_field(k)[::-1].copy() for k in range(4)]
+                c = g.cells[::-1].copy()
+                g.set_cell_types(c)
+                g.set_field(0, f[0]); g.set_field(1, f[1]); g.set_field(3, f[3])
+                g.set_field(2, -np.roll(f[2], 1, axis=0))   # w lives on low-z faces
+        a.project(); b.project()
+        a.semi_lagrange(0.02); b.semi_lagrange(0.02)
+        b.synchronize()
+        for k in range(4):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), (flip, k)
+    o.project_rb(stop_mode=0, max_iter=11)
+    del o

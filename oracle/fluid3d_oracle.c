@@ -791,15 +791,17 @@ int o3_project_rb(O3 *o, real omega, int stop_mode, double tol, int max_iter, in
     double metric = 0;
     if (check_every < 1) check_every = 1;
     for (;;) {
-        if (stop_mode == 1) {
+        /* either metric is evaluated after every check_every-th sweep and after the last one allowed */
+        const int check = (iter + 1) % check_every == 0 || iter + 1 >= max_iter;
+        if (stop_mode == 1 && check) {
             metric = o3_rb_sweep(o, omega);
         } else {
             o3_rb_halfsweep(o, 0, omega);
             o3_rb_halfsweep(o, 1, omega);
         }
         iter++;
-        if (stop_mode == 1 && !(metric > tol)) break;
-        if (stop_mode == 2 && (iter % check_every == 0 || iter >= max_iter)) {
+        if (stop_mode == 1 && check && !(metric > tol)) break;
+        if (stop_mode == 2 && check) {
             metric = o3_residual_l2(o);
             if (!(metric > tol)) break;
         }

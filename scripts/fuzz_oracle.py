@@ -1,0 +1,72 @@
+"""Random configurations of the GPU step against the CPU oracle, bit for bit: sizes (with and without tiles
+clear of the shell), kernel choices, both precisions, both step modes, the three stopping rules, omega, buoyancy.
+(The residual rule divides by dt inside a step; the oracle's projection takes tol * dt.)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fsamd_loader
+fs = fsamd_loader.load()
+from oracle.oracle3d import Oracle3D
+from tests.util3d import random_cells, random_field
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+t0, runs = time.time(), 0
+while time.time() - t0 < budget:
+    nx, ny, nz = int(rng.integers(3, 170)), int(rng.integers(3, 36)), int(rng.integers(3, 30))
+    dtype = int(rng.integers(0, 2))
+    cfg = dict(dtype=dtype, step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
+               advect_kernel=int(rng.integers(0, 2)), stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 9)),
+               check_every=int(rng.choice([1, 2, 3])), tol=float(rng.choice([5.0, 1e-1, 1e-3])),
+               omega=float(rng.choice([1.0, 1.0, 1.3])))
+    scale = float(rng.choice([1.0, 10.0, 60.0]))
+    dt = float(rng.choice([1.0 / 30.0, 0.02]))
+    npdt = np.float64 if dtype == 1 else np.float32
+    inner = int(rng.integers(1 << 30))
+    r2 = np.random.default_rng(inner)
+    shape = (nz, ny, nx)
+    cells = random_cells(shape, r2)
+    fields = [random_field(shape, r2, npdt, scale if k < 3 else 1.0) for k in range(4)]
+    fields[3] = np.abs(fields[3])
+    g = fs.FluidSim3D(nx, ny, nz, **cfg)
+    o = Oracle3D(nx, ny, nz, dtype=npdt)
+    o.cells[...] = cells
+    g.set_cell_types(cells)
+    for k in range(4):
+        o.field(k)[...] = fields[k]
+        g.set_field(k, fields[k])
+    otol = cfg["tol"] * (dt if cfg["stop_mode"] == 2 else 1.0)
+    def oproject():
+        return o.project_rb(omega=cfg["omega"], stop_mode=cfg["stop_mode"], tol=otol, max_iter=cfg["max_iters"],
+                            check_every=cfg["check_every"])
+    ok = True
+    for it in range(2):
+        g.advance(dt)
+        if cfg["step_mode"] == 0:
+            oproject(); o.semi_lagrange(dt)
+        else:
+            oproject()
+            u0 = [o.field(k).copy() for k in range(4)]
+            half = o.advect(0.5 * dt, u0, u0[:3], 0)
+            for k in range(4): o.field(k)[...] = half[k]
+            oproject()
+            uh = [o.field(k).copy() for k in range(3)]
+            refl = [o.reflect(uh[k], half[k]) for k in range(3)]
+            out = o.advect(0.5 * dt, refl + [o.field(3).copy()], uh, 0)
+            for k in range(4): o.field(k)[...] = out[k]
+        for k in range(4):
+            x, y = g.get_field(k), o.field(k)
+            if not np.array_equal(x, y) and not (np.array_equal(np.isnan(x), np.isnan(y)) and
+                                                 np.array_equal(np.nan_to_num(x), np.nan_to_num(y))):
+                print("MISMATCH", (nx, ny, nz), cfg, "scale", scale, "dt", dt, "seed", inner, "step", it, "field", k,
+                      int((x != y).sum()), flush=True)
+                ok = False
+        if not ok:
+            break
+    g.close()
+    runs += 1
+    if runs % 25 == 0:
+        print("  ...", runs, "configurations", flush=True)
+    if not ok:
+        sys.exit(1)
+print("fuzz ok:", runs, "configurations", flush=True)

@@ -18,7 +18,7 @@ while time.time() - t0 < budget:
     cfg = dict(dtype=dtype, step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
                advect_kernel=int(rng.integers(0, 2)), stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 9)),
                check_every=int(rng.choice([1, 2, 3])), tol=float(rng.choice([5.0, 1e-1, 1e-3])),
-               omega=float(rng.choice([1.0, 1.0, 1.3])))
+               omega=float(rng.choice([1.0, 1.0, 1.3])), advection=int(rng.integers(0, 2)))
     scale = float(rng.choice([1.0, 10.0, 60.0]))
     dt = float(rng.choice([1.0 / 30.0, 0.02]))
     npdt = np.float64 if dtype == 1 else np.float32
@@ -39,10 +39,26 @@ while time.time() - t0 < budget:
     def oproject():
         return o.project_rb(omega=cfg["omega"], stop_mode=cfg["stop_mode"], tol=otol, max_iter=cfg["max_iters"],
                             check_every=cfg["check_every"])
+    def advect_mc(t, q, vel):   # advection followed by the MacCormack correction and limiter over the same q, vel, t
+        return o.maccormack(t, q, vel, o.advect(t, q, vel, 0))
     ok = True
     for it in range(2):
         g.advance(dt)
-        if cfg["step_mode"] == 0:
+        if cfg["advection"] == 1:
+            oproject()
+            q0 = [o.field(k).copy() for k in range(4)]
+            if cfg["step_mode"] == 0:
+                m = advect_mc(dt, q0, q0[:3])
+            else:
+                m = advect_mc(0.5 * dt, q0, q0[:3])
+                for k in range(4): o.field(k)[...] = m[k]
+                tilde = [m[k].copy() for k in range(3)]
+                oproject()
+                uh = [o.field(k).copy() for k in range(3)]
+                refl = [o.reflect(uh[k], tilde[k]) for k in range(3)]
+                m = advect_mc(0.5 * dt, refl + [o.field(3).copy()], uh)
+            for k in range(4): o.field(k)[...] = m[k]
+        elif cfg["step_mode"] == 0:
             oproject(); o.semi_lagrange(dt)
         else:
             oproject()

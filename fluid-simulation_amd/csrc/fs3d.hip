@@ -848,6 +848,12 @@ int mg_vcycle(fs3d_sim* s) {
     const bool slabs = s->nparts_global > 1;
     const bool one_pass = s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS;
     FS_TRY(mg_prepare<T>(s));
+    // the cycle smooths with plain Gauss-Seidel: over-relaxation belongs to the sweeps-only solver
+    struct OmegaOne {
+        fs3d_sim* s; double saved;
+        explicit OmegaOne(fs3d_sim* sim) : s(sim), saved(sim->cfg.omega) { s->cfg.omega = 1.0; }
+        ~OmegaOne() { s->cfg.omega = saved; }
+    } plain(s);
     for (int k = 0; k < kMgNu1; ++k) FS_TRY(sweep_once<T>(s));
     if (slabs) {   // the residual of a slab's top plane reads w of its first halo plane
         halos_after_sweeps(s);

@@ -146,7 +146,8 @@ typedef struct fs3d_config {
                              fs3d_semi_lagrange stay the reference's semi-Lagrange)                */
     int32_t solver;       /* FS_SOLVER_*                                                          */
     double tol;           /* the reference uses 5.0 with FS_STOP_L1_CHANGE (main.cpp:108)         */
-    double omega;         /* over-relaxation factor; 1.0 = the reference's plain Gauss-Seidel     */
+    double omega;         /* over-relaxation factor of the sweeps; 1.0 = the reference's plain
+                             Gauss-Seidel (multigrid cycles always smooth with 1.0)               */
     double buoyancy;      /* 0 = off; else the 0.1 of 3_fluid/FluidSim.h:115 scaled by this value */
 } fs3d_config;
 

@@ -79,6 +79,14 @@ while time.time() - t0 < budget:
                 ok = False
         if not ok:
             break
+    if ok:   # one multigrid cycle on whatever the steps left
+        o.mg_vcycle(2, 2, 30, 2.0); g.mg_vcycle()
+        for k in range(3):
+            x, y = g.get_field(k), o.field(k)
+            if not (np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.nan_to_num(x), np.nan_to_num(y))):
+                print("MISMATCH after a multigrid cycle", (nx, ny, nz), cfg, "scale", scale, "seed", inner, "field", k,
+                      int((x != y).sum()), flush=True)
+                ok = False
     g.close()
     runs += 1
     if runs % 25 == 0:

@@ -111,6 +111,11 @@ void o2_add_buoyancy(O2 *o) {
             V_(o->fy, i, j) += 0.1 * (C_(o->d, i, j - 1) + C_(o->d, i, j)) / 2.0 * scaling;
 }
 
+/* FluidSim.h:123-124: the reference's call counter is a function-level static, so one per process, shared by every
+   FluidSim in it and never reset. The oracle keeps one per simulation (the same thing for a process that holds one
+   FluidSim); a checker that drives several reference instances in one process carries the count over with this. */
+void o2_set_wind_calls(O2 *o, double r) { o->wind_r = r; }
+
 /* FluidSim.h:120-134 */
 void o2_add_wind(O2 *o) {
     const double scaling = 64.0 / o->rx;

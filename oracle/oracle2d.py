@@ -117,6 +117,7 @@ class Oracle2D(_Sim2D):
             Oracle2D.lib.o2_last_iters.argtypes = [C.c_void_p]
             Oracle2D.lib.o2_last_residual.restype = C.c_double
             Oracle2D.lib.o2_last_residual.argtypes = [C.c_void_p]
+            Oracle2D.lib.o2_set_wind_calls.argtypes = [C.c_void_p, C.c_double]
         super().__init__(rx, ry)
 
     def _get(self, which, a): self.lib.o2_get(self.h, which, a.ctypes.data_as(C.c_void_p))
@@ -124,6 +125,11 @@ class Oracle2D(_Sim2D):
 
     def advance(self, red_black=False):
         self.lib.o2_advance(self.h, int(red_black))
+
+    def set_wind_calls(self, r):
+        """addWind's call counter (a process-wide static in the reference, FluidSim.h:123): for checks that run
+        several reference instances in one process."""
+        self.lib.o2_set_wind_calls(self.h, float(r))
 
     @property
     def last_iters(self): return self.lib.o2_last_iters(self.h)

@@ -1,6 +1,9 @@
 """Random configurations of the slab path against the single domain, bit for bit (a search for corner cases:
-slabs of two or three planes, odd sizes, every kernel choice, both precisions, the deferred evaluation, multigrid)."""
-import os, sys, time
+slabs of two or three planes, odd sizes, every kernel choice, both precisions, the deferred evaluation, multigrid).
+One configuration in three also writes a restart file after the first step and continues it on a third simulation
+with yet another slab count; diagnostics (sums to 1e-12, the maximum exactly) and block-averaged density are compared
+at the end."""
+import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import fsamd_loader
@@ -9,7 +12,8 @@ from tests.util3d import random_cells, random_field
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
-t0, runs, skipped = time.time(), 0, 0
+t0, runs, skipped, restarts = time.time(), 0, 0, 0
+tmp = tempfile.mkdtemp()
 while time.time() - t0 < budget:
     nx, ny, nz = int(rng.integers(6, 150)), int(rng.integers(5, 40)), int(rng.integers(6, 48))
     slabs = int(rng.integers(2, 9))
@@ -36,15 +40,52 @@ while time.time() - t0 < budget:
         for k in range(4):
             g.set_field(k, fields[k])
     ok = True
+    c = None
     try:
         for it in range(3):
             a.advance(0.02); b.advance(0.02)
             b.synchronize()    # a backtrace beyond the slab halo is reported here (and is no mismatch)
+            if c is not None:
+                c.advance(0.02); c.synchronize()
             if a.stats().sweeps_step != b.stats().sweeps_step:
                 ok = False
             for k in range(4):
-                if not np.array_equal(a.get_field(k), b.get_field(k)):
+                want = a.get_field(k)
+                if not np.array_equal(want, b.get_field(k)):
                     ok = False
+                if c is not None and not np.array_equal(want, c.get_field(k)):
+                    print("RESTART MISMATCH field", k, flush=True)
+                    ok = False
+            if c is not None and c.stats().sweeps_step != a.stats().sweeps_step:
+                print("RESTART MISMATCH sweeps", c.stats().sweeps_step, a.stats().sweeps_step, flush=True)
+                ok = False
+            if it == 0 and ok and rng.integers(0, 3) == 0:
+                try:
+                    c = fs.FluidSim3D(nx, ny, nz, local_slabs=int(rng.integers(1, 6)), **cfg)
+                except fs.FluidSimError:
+                    c = None
+                if c is not None:
+                    path = os.path.join(tmp, "state.fs3d")
+                    (a if rng.integers(0, 2) else b).save(path)
+                    c.load(path)
+                    restarts += 1
+        if ok:
+            da, db = a.diagnostics(), b.diagnostics()
+            for name in ("kinetic_energy", "density_sum", "enstrophy"):
+                x, y = getattr(da, name), getattr(db, name)
+                if not (abs(x - y) <= 1e-12 * max(abs(x), abs(y)) or (np.isnan(x) and np.isnan(y))):
+                    print("DIAGNOSTICS MISMATCH", name, x, y, flush=True)
+                    ok = False
+            if not (da.max_speed == db.max_speed or (np.isnan(da.max_speed) and np.isnan(db.max_speed))):
+                print("DIAGNOSTICS MISMATCH max_speed", da.max_speed, db.max_speed, flush=True)
+                ok = False
+            try:
+                small = b.downsample_density(2)
+            except fs.FluidSimError:
+                small = None       # slab boundaries on odd planes
+            if small is not None and not np.array_equal(small, a.downsample_density(2)):
+                print("DOWNSAMPLE MISMATCH", flush=True)
+                ok = False
             if not ok:
                 print("MISMATCH", (nx, ny, nz), slabs, cfg, scale, "seed", inner, "step", it, a.stats().sweeps_step, b.stats().sweeps_step, flush=True)
                 break
@@ -53,9 +94,11 @@ while time.time() - t0 < budget:
             print("ERROR", (nx, ny, nz), slabs, cfg, scale, e, flush=True)
             ok = False
     a.close(); b.close()
+    if c is not None:
+        c.close()
     runs += 1
     if runs % 25 == 0:
         print("  ...", runs, "configurations", flush=True)
     if not ok:
         sys.exit(1)
-print("fuzz ok:", runs, "configurations,", skipped, "rejected at creation", flush=True)
+print("fuzz ok:", runs, "configurations,", restarts, "continued from a restart file,", skipped, "rejected at creation", flush=True)

@@ -12,10 +12,13 @@ from tests.util3d import random_cells, random_field
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 t0, runs, skipped, restarts = time.time(), 0, 0, 0
 tmp = tempfile.mkdtemp()
 while time.time() - t0 < budget:
     nx, ny, nz = int(rng.integers(6, 150)), int(rng.integers(5, 40)), int(rng.integers(6, 48))
+    if WIDE:      # long rows (several x tiles, both row-segment variants of the sweep), few of them
+        nx, ny, nz = int(rng.integers(150, 700)), int(rng.integers(5, 12)), int(rng.integers(6, 20))
     slabs = int(rng.integers(2, 9))
     cfg = dict(dtype=int(rng.integers(0, 2)), step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
                advect_kernel=int(rng.integers(0, 2)), advection=int(rng.integers(0, 2)),

@@ -13,13 +13,16 @@ from tests.util3d import random_cells, random_field
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
+TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
 t0, runs, skipped, restarts = time.time(), 0, 0, 0
 tmp = tempfile.mkdtemp()
 while time.time() - t0 < budget:
     nx, ny, nz = int(rng.integers(6, 150)), int(rng.integers(5, 40)), int(rng.integers(6, 48))
     if WIDE:      # long rows (several x tiles, both row-segment variants of the sweep), few of them
         nx, ny, nz = int(rng.integers(150, 700)), int(rng.integers(5, 12)), int(rng.integers(6, 20))
-    slabs = int(rng.integers(2, 9))
+    slabs = int(rng.integers(2, 17 if TALL else 9))
+    if TALL:      # many planes of few cells (several z chunks per launch, many slabs)
+        nx, ny, nz = int(rng.integers(6, 40)), int(rng.integers(5, 16)), int(rng.integers(40, 400))
     cfg = dict(dtype=int(rng.integers(0, 2)), step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
                advect_kernel=int(rng.integers(0, 2)), advection=int(rng.integers(0, 2)),
                stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 12)),

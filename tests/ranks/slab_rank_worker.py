@@ -19,18 +19,24 @@ def main():
     import fsamd_loader
     fs = fsamd_loader.load()
     from tests import slab_scenarios as sc
-    id_path = out_path + ".id"
-    if rank == 0:
-        with open(id_path + ".tmp", "wb") as f:
-            f.write(fs.comm_unique_id())
-        os.replace(id_path + ".tmp", id_path)
-    deadline = time.time() + 120
-    while not os.path.exists(id_path):
-        if time.time() > deadline:
-            raise SystemExit("no communicator id from rank 0")
-        time.sleep(0.01)
-    comm_id = open(id_path, "rb").read()
-    record = sc.run(fs, scenario, rank=rank, nranks=world, comm_id=comm_id)
+    def comm_id_for(i):
+        """The i-th communicator id of this run: rank 0 makes it, the others wait for its file."""
+        id_path = f"{out_path}.id{i}"
+        if rank == 0:
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(fs.comm_unique_id())
+            os.replace(id_path + ".tmp", id_path)
+        deadline = time.time() + 120
+        while not os.path.exists(id_path):
+            if time.time() > deadline:
+                raise SystemExit("no communicator id from rank 0")
+            time.sleep(0.005)
+        return open(id_path, "rb").read()
+
+    if scenario.startswith("random:"):
+        record = sc.run(fs, scenario, rank=rank, nranks=world, comm_ids=comm_id_for)
+    else:
+        record = sc.run(fs, scenario, rank=rank, nranks=world, comm_id=comm_id_for(0))
     np.savez(f"{out_path}.rank{rank}.npz", **{k: np.asarray(v) for k, v in record.items()})
     print(f"rank {rank} done", flush=True)
 

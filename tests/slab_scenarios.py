@@ -102,5 +102,39 @@ SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, s
                                      vortex_ring_deferred, vortex_ring_multigrid)}
 
 
-def run(fs, name, rank=0, nranks=1, comm_id=None):
+def random_configurations(fs, seed, world, count, rank=0, nranks=1, comm_ids=None):
+    """`count` random configurations drawn from `seed` for a run on `world` ranks (the single domain draws the same
+    ones): sizes, precision, kernels, step mode, advection scheme, stopping rule and schedule, solver. `comm_ids(i)`
+    gives the communicator id of the i-th configuration."""
+    rng = np.random.default_rng(seed)
+    rec = {}
+    for i in range(count):
+        nx, ny = int(rng.integers(6, 90)), int(rng.integers(5, 30))
+        nz = int(rng.integers(3 * world, 12 * world))
+        cfg = dict(dtype=int(rng.integers(0, 2)), step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
+                   advect_kernel=int(rng.integers(0, 2)), advection=int(rng.integers(0, 2)),
+                   stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 12)),
+                   check_every=int(rng.choice([-1, 0, 1, 3])), tol=float(rng.choice([1.0, 1e-2, 1e-4])))
+        cfg["solver"] = int(rng.integers(0, 2)) if cfg["stop_mode"] != 1 else 0
+        if cfg["solver"] == 1:
+            nz = 2 * world * int(rng.integers(2, 6))        # multigrid wants slab interfaces on even planes
+        scale, inner = float(rng.choice([1.0, 10.0, 20.0])), int(rng.integers(1 << 30))
+        dt = np.float64 if cfg["dtype"] == 1 else np.float32
+        g = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=nranks, comm_id=comm_ids(i) if nranks > 1 else None, device=0, **cfg)
+        r2 = np.random.default_rng(inner)
+        shape = (nz, ny, nx)
+        g.set_cell_types(random_cells(shape, r2)[g.z0:g.z1])
+        for k in range(4):
+            g.set_field(k, random_field(shape, r2, dt, scale if k < 3 else 1.0)[g.z0:g.z1])
+        for step in range(3):
+            g.advance(0.02)
+            _snapshot(g, rec, f"c{i}s{step}")
+        g.close()
+    return rec
+
+
+def run(fs, name, rank=0, nranks=1, comm_id=None, comm_ids=None):
+    if name.startswith("random:"):       # random:<seed>:<world>:<count>
+        seed, world, count = map(int, name.split(":")[1:])
+        return random_configurations(fs, seed, world, count, rank=rank, nranks=nranks, comm_ids=comm_ids)
     return SCENARIOS[name](fs, rank=rank, nranks=nranks, comm_id=comm_id)

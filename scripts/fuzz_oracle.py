@@ -13,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
+FAST = len(sys.argv) > 3 and sys.argv[3] == "fast"
 t0, runs = time.time(), 0
 while time.time() - t0 < budget:
     nx, ny, nz = int(rng.integers(3, 170)), int(rng.integers(3, 36)), int(rng.integers(3, 30))
@@ -26,6 +27,8 @@ while time.time() - t0 < budget:
                check_every=int(rng.choice([1, 2, 3])), tol=float(rng.choice([5.0, 1e-1, 1e-3])),
                omega=float(rng.choice([1.0, 1.0, 1.3])), advection=int(rng.integers(0, 2)))
     scale = float(rng.choice([1.0, 10.0, 60.0]))
+    if FAST:      # backtraces of many cells: beyond the staged planes of the tiled advection, out of the domain
+        scale = float(rng.choice([150.0, 400.0, 2000.0]))
     dt = float(rng.choice([1.0 / 30.0, 0.02]))
     npdt = np.float64 if dtype == 1 else np.float32
     inner = int(rng.integers(1 << 30))

@@ -44,14 +44,26 @@ while time.time() - t0 < budget:
     for k in range(4):
         o.field(k)[...] = fields[k]
         g.set_field(k, fields[k])
-    otol = cfg["tol"] * (dt if cfg["stop_mode"] == 2 else 1.0)
     def oproject():
+        otol = cfg["tol"] * (dt if cfg["stop_mode"] == 2 else 1.0)
         return o.project_rb(omega=cfg["omega"], stop_mode=cfg["stop_mode"], tol=otol, max_iter=cfg["max_iters"],
                             check_every=cfg["check_every"])
     def advect_mc(t, q, vel):   # advection followed by the MacCormack correction and limiter over the same q, vel, t
         return o.maccormack(t, q, vel, o.advect(t, q, vel, 0))
     ok = True
-    for it in range(2):
+    for it in range(3):
+        if it and rng.integers(0, 2):      # the configuration changes between steps
+            new = dict(step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
+                       advect_kernel=int(rng.integers(0, 2)), stop_mode=int(rng.choice([0, 1, 2])),
+                       max_iters=int(rng.integers(1, 9)), check_every=int(rng.choice([1, 2, 3])),
+                       tol=float(rng.choice([5.0, 1e-1, 1e-3])), omega=float(rng.choice([1.0, 1.0, 1.3])),
+                       advection=int(rng.integers(0, 2)))
+            new = {k: v for k, v in new.items() if rng.integers(0, 2)}
+            try:
+                g.set_config(**new)
+                cfg.update(new)
+            except fs.FluidSimError:
+                g.set_config(**{k: cfg[k] for k in new})      # back to what it was
         g.advance(dt)
         if cfg["advection"] == 1:
             oproject()

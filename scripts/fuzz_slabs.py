@@ -49,6 +49,21 @@ while time.time() - t0 < budget:
     c = None
     try:
         for it in range(3):
+            if it and rng.integers(0, 2):      # the configuration changes between steps, on every simulation alike
+                new = dict(step_mode=int(rng.integers(0, 2)), sweep_kernel=int(rng.integers(0, 3)),
+                           advect_kernel=int(rng.integers(0, 2)), advection=int(rng.integers(0, 2)),
+                           stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 12)),
+                           check_every=int(rng.choice([-1, 0, 1, 3])), tol=float(rng.choice([1.0, 1e-2, 1e-4])),
+                           solver=int(rng.integers(0, 2)))
+                new = {k: v for k, v in new.items() if rng.integers(0, 2)}
+                sims = [g for g in (a, b, c) if g is not None]
+                try:
+                    for g in sims:
+                        g.set_config(**new)
+                    cfg.update(new)
+                except fs.FluidSimError:
+                    for g in sims:
+                        g.set_config(**{k: cfg[k] for k in new})      # back to what it was
             a.advance(0.02); b.advance(0.02)
             b.synchronize()    # a backtrace beyond the slab halo is reported here (and is no mismatch)
             if c is not None:

@@ -33,6 +33,7 @@ def main():
             time.sleep(0.005)
         return open(id_path, "rb").read()
 
+    os.environ["FSAMD_TEST_RESTART_PATH"] = out_path + ".restart"
     if scenario.startswith("random:"):
         record = sc.run(fs, scenario, rank=rank, nranks=world, comm_ids=comm_id_for)
     else:

@@ -1,6 +1,9 @@
 """Scenarios run identically by a single-domain simulation and by the ranks of a multi-process z-slab run; each
 returns a dict of owned-plane fields (3D arrays, concatenated over ranks by the caller) and scalars (which must
 agree on every rank)."""
+import os
+import tempfile
+
 import numpy as np
 
 from tests.util3d import random_cells, random_field
@@ -59,6 +62,11 @@ def steps_residual(fs, **kw):
     d = g.diagnostics()
     rec["diag"] = np.array([getattr(d, f[0]) for f in d._fields_], dtype=np.float64)
     rec["vort"] = g.vorticity()
+    # the restart file: one file, every rank writes its own planes (FSAMD_TEST_RESTART_PATH: the same path on every rank)
+    path = os.environ.get("FSAMD_TEST_RESTART_PATH") or os.path.join(tempfile.mkdtemp(), "state.fs3d")
+    g.save(path)
+    g.residual()          # an all-reduce: every rank has written its planes when it returns
+    rec["restart_file"] = np.fromfile(path, dtype=np.uint8)
     g.close()
     return rec
 

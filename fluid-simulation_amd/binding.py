@@ -34,6 +34,7 @@ ADVECT_TILED, ADVECT_DIRECT = 0, 1
 ADVECTION_SEMI_LAGRANGE, ADVECTION_MACCORMACK = 0, 1
 SOLVER_SWEEPS, SOLVER_MULTIGRID = 0, 1
 COMM_ID_BYTES = 128
+NOALLOC_MAX_CELLS = 1 << 24
 
 # every symbol include/fluidsim_amd.h declares
 EXPORTS = [
@@ -43,7 +44,8 @@ EXPORTS = [
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
-    "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fsamd_comm_unique_id", "fsamd_comm_selftest",
+    "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fs3d_residual_noalloc",
+    "fsamd_comm_unique_id", "fsamd_comm_selftest",
     "fs3d_create_slab", "fs3d_slab_range",
     "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
     "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
@@ -128,6 +130,7 @@ def load_library(path=None):
         "fs3d_mg_vcycle": (I, [P]),
         "fs3d_save": (I, [P, C.c_char_p]),
         "fs3d_load": (I, [P, C.c_char_p]),
+        "fs3d_residual_noalloc": (I, [I, I, I, I, I, P, P, P, P, P, P]),
         "fsamd_comm_unique_id": (I, [P]),
         "fsamd_comm_selftest": (I, [I]),
         "fs3d_create_slab": (I, [I, I, I, C.POINTER(Config), I, I, P, C.POINTER(P)]),

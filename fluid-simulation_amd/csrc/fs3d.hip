@@ -1585,6 +1585,9 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     return FS_OK;
 }
 
+// The text of the last failure of a call that takes no handle, per host thread (fs3d_last_error(NULL)).
+thread_local std::string g_handleless_err;
+
 }  // namespace
 
 // ===========================================================================
@@ -1763,7 +1766,10 @@ int fs3d_get_config(const fs3d_sim* s, fs3d_config* c) {
     return FS_OK;
 }
 
-const char* fs3d_last_error(const fs3d_sim* s) { return s ? s->err.c_str() : "null handle"; }
+const char* fs3d_last_error(const fs3d_sim* s) {
+    if (s) return s->err.c_str();
+    return g_handleless_err.empty() ? "null handle" : g_handleless_err.c_str();
+}
 
 int fs3d_set_field(fs3d_sim* s, int which, const void* host, size_t count) {
     SIM_GUARD(s);
@@ -2131,4 +2137,103 @@ int fs3d_synchronize(fs3d_sim* s) {
     return oob_status(s);
 }
 
+
 }  // extern "C"
+
+// ===========================================================================
+// fs3d_residual_noalloc: the residual of fs3d_residual for callers that cannot allocate (code under HIP
+// graph capture, tight serving loops).  The caller passes device arrays; everything else the kernels need
+// beyond inputs and outputs (the flag bytes derived from the cell types, the per-workgroup partial sums
+// and the combined pair) lives in a file-scope device array of fixed size.  Every GPU holds its own copy
+// of that array at its own address: the address is looked up once per device, with that device current,
+// and only the looked-up pointer is ever handed to a kernel (the array's name is a host-side stand-in,
+// not a device address).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
+namespace {
+
+constexpr size_t kNoallocMaxCells = (size_t)FS_NOALLOC_MAX_CELLS;
+constexpr size_t kNoallocPartials = 2 * (size_t)kReduceBlocks * sizeof(double);
+constexpr size_t kNoallocBytes = kNoallocMaxCells + kNoallocPartials + 256;   // flags | partials | pair
+
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
+
+constexpr int kNoallocMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kNoallocMaxDevices] = {nullptr};
+
+// The device address of `scratch` on `device`, which must be the current device.
+int scratch_on_device(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            g_handleless_err = hip_err("hipGetSymbolAddress(scratch)", e, __FILE__, __LINE__);
+            return FS_EHIP;
+        }
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return FS_OK;
+}
+
+// out[0] = sqrt(sum) / #interior (3_fluid/FluidSim.cpp:40-43), out[1] = max |div|
+__global__ void k_residual_finish(const double* __restrict__ pair, double ninterior, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = sqrt(pair[0]) / ninterior;
+        out[1] = pair[1];
+    }
+}
+
+template <typename T>
+int residual_noalloc(int nx, int ny, int nz, const void* u, const void* v, const void* w, const uint8_t* cells,
+                     unsigned char* sc, double* out, hipStream_t st) {
+    Grid g{};
+    g.nx = nx; g.ny = ny; g.nzl = nz; g.gz0 = 0; g.gnz = nz;
+    g.sy = nx; g.sz = (int64_t)nx * ny;
+    uint8_t* flags = sc;
+    double* partials = reinterpret_cast<double*>(sc + kNoallocMaxCells);
+    double* pair = reinterpret_cast<double*>(sc + kNoallocMaxCells + kNoallocPartials);
+    // every kernel below writes all of what the next one reads (flags of every cell, one partial pair per
+    // workgroup, the combined pair), so nothing has to start at zero
+    dim3 b(64, 4, 1), gf(div_up(nx, 64), div_up(ny, 4), nz);
+    hipLaunchKernelGGL(k_build_flags, gf, b, 0, st, g, cells, flags);
+    hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, st, g, (const T*)u, (const T*)v, (const T*)w,
+                       (const uint8_t*)flags, 1, nz - 1, partials, (T*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, (const double*)partials, kReduceBlocks, pair);
+    hipLaunchKernelGGL(k_residual_finish, dim3(1), dim3(64), 0, st, (const double*)pair,
+                       (double)(nx - 2) * (ny - 2) * (nz - 2), out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_handleless_err = hip_err("kernel launch", e, __FILE__, __LINE__);
+        return FS_EHIP;
+    }
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" int fs3d_residual_noalloc(int device, int nx, int ny, int nz, int dtype, const void* d_u, const void* d_v,
+                                     const void* d_w, const uint8_t* d_cells, double* d_out, void* stream) {
+    g_handleless_err.clear();
+    if (nx < 3 || ny < 3 || nz < 3 || (dtype != FS_F32 && dtype != FS_F64) || !d_u || !d_v || !d_w || !d_cells || !d_out) {
+        g_handleless_err = "fs3d_residual_noalloc: bad size, element type or null pointer";
+        return FS_EINVAL;
+    }
+    if ((size_t)nx * (size_t)ny * (size_t)nz > kNoallocMaxCells) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "fs3d_residual_noalloc: %d x %d x %d cells exceed the fixed scratch of %zu cells "
+                 "(FS_NOALLOC_MAX_CELLS); use fs3d_residual on a handle", nx, ny, nz, kNoallocMaxCells);
+        g_handleless_err = buf;
+        return FS_EINVAL;
+    }
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { g_handleless_err = "hipGetDevice failed"; return FS_EHIP; }
+    if (dev >= kNoallocMaxDevices) { g_handleless_err = "device ordinal beyond the table of scratch addresses"; return FS_EINVAL; }
+    DeviceGuard guard(dev);
+    if (!guard.ok) { g_handleless_err = "hipSetDevice failed"; return FS_EHIP; }
+    unsigned char* sc = nullptr;
+    FS_TRY(scratch_on_device(dev, &sc));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FS_F64) return residual_noalloc<double>(nx, ny, nz, d_u, d_v, d_w, d_cells, sc, d_out, st);
+    return residual_noalloc<float>(nx, ny, nz, d_u, d_v, d_w, d_cells, sc, d_out, st);
+}

@@ -276,6 +276,22 @@ int fs3d_get_density_downsampled(fs3d_sim *sim, int factor, void *host, size_t c
 int fs3d_save(fs3d_sim *sim, const char *path);
 int fs3d_load(fs3d_sim *sim, const char *path);
 
+/* The residual of fs3d_residual without a handle and without any allocation.  It has no counterpart in the
+ * reference; it is for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  The caller passes device arrays of a whole nx*ny*nz grid on GPU `device`
+ * (-1 = the calling thread's current device): u, v, w of element type `dtype` (FS_F32 / FS_F64), the cell
+ * types (one byte per cell, FS_CELL_*, shell included) and d_out, two doubles in device memory that receive
+ * the L2 residual sqrt(sum div^2)/#interior and max |div| (what fs3d_residual returns).  All arrays x fastest
+ * and 16-byte aligned.  The kernels are queued on `stream` (a hipStream_t, NULL = the null stream) and the
+ * call returns without waiting.  What the kernels need beyond inputs and outputs (flag bytes, partial sums)
+ * lives in a fixed device array of FS_NOALLOC_MAX_CELLS + 16 KiB bytes that every GPU the entry point is used
+ * on holds until the process ends: grids of more cells are refused with FS_EINVAL (text by
+ * fs3d_last_error(NULL), per host thread).  No hipMalloc, hipFree or other allocating call is made.  All
+ * calls on one GPU share that array: calls that overlap on one GPU (from several streams or threads) race. */
+#define FS_NOALLOC_MAX_CELLS (1u << 24)   /* 256^3 */
+int fs3d_residual_noalloc(int device, int nx, int ny, int nz, int dtype, const void *d_u, const void *d_v,
+                          const void *d_w, const uint8_t *d_cells, double *d_out, void *stream);
+
 /* z-slab decomposition over the GPUs of one node (no counterpart in the
  * reference, which is single-process) ------------------------------------- */
 #define FS_COMM_ID_BYTES 128

@@ -42,11 +42,11 @@ EXPORTS = [
     "fs3d_get_config", "fs3d_last_error", "fs3d_set_field", "fs3d_get_field", "fs3d_get_field_plane",
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
-    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
+    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
     "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fs3d_residual_noalloc",
     "fsamd_comm_unique_id", "fsamd_comm_selftest",
-    "fs3d_create_slab", "fs3d_slab_range",
+    "fs3d_create_slab", "fs3d_slab_range", "fs3d_comm_timing", "fs3d_get_comm_stats",
     "fs2d_create", "fs2d_destroy", "fs2d_last_error", "fs2d_reset", "fs2d_set_params", "fs2d_get_info",
     "fs2d_field_size", "fs2d_get_field", "fs2d_set_field", "fs2d_advance", "fs2d_stage",
 ]
@@ -67,6 +67,12 @@ class Stats(C.Structure):
         ("metric", C.c_double), ("ms_project", C.c_double), ("ms_advect", C.c_double), ("ms_step", C.c_double),
         ("evaluations_step", C.c_int32), ("redone", C.c_int32),
     ]
+
+
+class CommStats(C.Structure):
+    _fields_ = [("exchanges", C.c_int64), ("waits", C.c_int64), ("reductions", C.c_int64), ("bytes_sent_lo", C.c_int64),
+                ("bytes_sent_hi", C.c_int64), ("exchange_ms", C.c_double), ("wait_ms", C.c_double),
+                ("reduction_host_ms", C.c_double)]
 
 
 class Diag(C.Structure):
@@ -118,6 +124,7 @@ def load_library(path=None):
         "fs3d_gauss_seidel_projection": (I, [P, C.POINTER(D)]),
         "fs3d_sweeps": (I, [P, I]),
         "fs3d_time_sweeps": (I, [P, I, C.POINTER(D)]),
+        "fs3d_time_advections": (I, [P, I, D, I, C.POINTER(D)]),
         "fs3d_project": (I, [P, C.POINTER(I), C.POINTER(D)]),
         "fs3d_residual": (I, [P, C.POINTER(D), C.POINTER(D)]),
         "fs3d_semi_lagrange": (I, [P, D]),
@@ -135,6 +142,8 @@ def load_library(path=None):
         "fsamd_comm_selftest": (I, [I]),
         "fs3d_create_slab": (I, [I, I, I, C.POINTER(Config), I, I, P, C.POINTER(P)]),
         "fs3d_slab_range": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
+        "fs3d_comm_timing": (I, [P, I]),
+        "fs3d_get_comm_stats": (I, [P, C.POINTER(CommStats), I]),
         "fs2d_create": (I, [I, I, I, C.POINTER(P)]),
         "fs2d_destroy": (None, [P]),
         "fs2d_last_error": (C.c_char_p, [P]),
@@ -333,6 +342,11 @@ class FluidSim3D:
         self._chk(self.lib.fs3d_time_sweeps(self.h, n, C.byref(ms)))
         return ms.value
 
+    def time_advections(self, n, t_step, reflected=False):
+        ms = C.c_double()
+        self._chk(self.lib.fs3d_time_advections(self.h, n, t_step, int(reflected), C.byref(ms)))
+        return ms.value
+
     def project(self):
         n, m = C.c_int(), C.c_double()
         self._chk(self.lib.fs3d_project(self.h, C.byref(n), C.byref(m)))
@@ -374,6 +388,14 @@ class FluidSim3D:
 
     def synchronize(self):
         self._chk(self.lib.fs3d_synchronize(self.h))
+
+    def comm_timing(self, on=True):
+        self._chk(self.lib.fs3d_comm_timing(self.h, int(on)))
+
+    def comm_stats(self, reset=False):
+        st = CommStats()
+        self._chk(self.lib.fs3d_get_comm_stats(self.h, C.byref(st), int(reset)))
+        return st
 
 
 class FluidSim2D:

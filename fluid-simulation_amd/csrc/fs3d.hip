@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -89,10 +90,9 @@ struct fs3d_sim {
                                  // unprojected half-step field (else it is in the scratch fields, or not needed)
     bool cells_dirty = true;
     int halo_dirty = 7;          // halo planes that lag their owners: bit 0 velocity, bit 1 density, bit 2 scratch velocity
-    double* dres = nullptr;      // 2 doubles per local part + 2 combined
-    double* hres = nullptr;      // pinned mirror of the combined pair
-    int* doob = nullptr;         // device flag: a backtrace left the slab's halo
-    int* hoob = nullptr;
+    double* dres = nullptr;      // 2 doubles per local part, then the combined record: sum, out-of-halo count, max
+    double* hres = nullptr;      // pinned mirror of the combined record
+    int* doob = nullptr;         // device flag the advection kernels raise: a backtrace left the slab's halo
     ncclComm_t comm = nullptr;
     ncclComm_t comm_red = nullptr;   // the communicator of the scalar all-reduces: a copy of `comm` where the library
                                      // can make one (the reductions then need not queue behind the halo traffic), else `comm`
@@ -104,6 +104,13 @@ struct fs3d_sim {
     int sweep_hint_prev[2] = {0, 0};   // and of the step before that
     double resid_dt = 1.0;       // the dt in b = -div/dt of the L2 residual (3_fluid/FluidSim.cpp:17)
     std::string err;
+    // Communication accounting (fs3d_get_comm_stats).  Byte and call counts are always kept; device times need
+    // event pairs around every exchange and every wait, which is switched on by fs3d_comm_timing.
+    struct Timed { hipEvent_t a = nullptr, b = nullptr; int kind = 0; bool busy = false; };
+    std::vector<Timed> timed;    // ring of event pairs
+    size_t timed_next = 0;
+    bool comm_timing = false;
+    fs3d_comm_stats cstats{};
 };
 
 // Raises a kernel's dynamic LDS limit once per kernel and device (the call is not free, and a sweep
@@ -219,6 +226,36 @@ int zero_fields(fs3d_sim* s) {
     return FS_OK;
 }
 
+// ---- communication accounting ------------------------------------------------
+void timed_resolve(fs3d_sim* s, fs3d_sim::Timed& t) {
+    if (!t.busy) return;
+    float ms = 0;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess)
+        (t.kind == 0 ? s->cstats.exchange_ms : s->cstats.wait_ms) += ms;
+    t.busy = false;
+}
+
+// Records the first event of a pair on `st` and returns the pair (nullptr when timing is off); timed_end
+// records the second.  kind 0: an exchange on the communication stream, 1: the main stream waiting for one.
+fs3d_sim::Timed* timed_begin(fs3d_sim* s, hipStream_t st, int kind) {
+    if (!s->comm_timing) return nullptr;
+    if (s->timed.empty()) {
+        s->timed.resize(256);
+        for (auto& t : s->timed)
+            if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { s->comm_timing = false; return nullptr; }
+    }
+    fs3d_sim::Timed& t = s->timed[s->timed_next];
+    s->timed_next = (s->timed_next + 1) % s->timed.size();
+    timed_resolve(s, t);   // the oldest pair: long finished
+    t.kind = kind;
+    if (hipEventRecord(t.a, st) != hipSuccess) return nullptr;
+    return &t;
+}
+
+void timed_end(fs3d_sim::Timed* t, hipStream_t st) {
+    if (t && hipEventRecord(t->b, st) == hipSuccess) t->busy = true;
+}
+
 // ---- halo transport -------------------------------------------------------
 // Copies `planes` planes of `bytes_per_plane` bytes between neighbouring parts:
 // from local plane src_lz of part a into local plane dst_lz of part b, for
@@ -231,9 +268,19 @@ struct HaloOp {
     size_t elem = 1;
 };
 
+int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st);
+
 int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st = nullptr) {
     if (s->nparts_global == 1) return FS_OK;
     if (!st) st = s->stream;
+    fs3d_sim::Timed* t = timed_begin(s, st, 0);
+    const int rc = exchange_halos_impl(s, ops, st);
+    timed_end(t, st);
+    ++s->cstats.exchanges;
+    return rc;
+}
+
+int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st) {
     bool remote = false;
     for (Part& p : s->parts) {
         const size_t H = p.H;
@@ -264,12 +311,14 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st =
             char* a = (char*)op.base(s, lo, op.which);
             FS_TRY(nccl_check(s, R->Send(a + H * plane, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclSend"));
             FS_TRY(nccl_check(s, R->Recv(a, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclRecv"));
+            s->cstats.bytes_sent_lo += (int64_t)(H * plane);
         }
         if (hi.has_hi) {
             const size_t plane = (size_t)hi.g.sz * op.elem, H = hi.H;
             char* a = (char*)op.base(s, hi, op.which);
             FS_TRY(nccl_check(s, R->Send(a + (size_t)hi.own_planes() * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclSend"));
             FS_TRY(nccl_check(s, R->Recv(a + (H + hi.own_planes()) * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclRecv"));
+            s->cstats.bytes_sent_hi += (int64_t)(H * plane);
         }
     }
     return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
@@ -287,7 +336,10 @@ enum { HALO_VEL = 1, HALO_DEN = 2, HALO_ALL = 3, HALO_TMP = 4 };
 // halo planes, touches the communicator or hands data to the host calls join_halos first.
 int join_halos(fs3d_sim* s) {
     if (!s->halo_pending) return FS_OK;
+    fs3d_sim::Timed* t = timed_begin(s, s->stream, 1);
     SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    timed_end(t, s->stream);
+    ++s->cstats.waits;
     s->halo_pending = false;
     return FS_OK;
 }
@@ -614,18 +666,24 @@ int sweep_once(fs3d_sim* s) {
 }
 
 // Combines the per-part (sum, max) pairs, across ranks too, into host values.
-__global__ void k_combine_parts(const double* __restrict__ dres, int nparts, double* __restrict__ out) {
+// out[0] = sum, out[1] = 1 if this process's out-of-halo flag is up (added over the ranks with the sum: every rank
+// then sees the same count), out[2] = max.
+__global__ void k_combine_parts(const double* __restrict__ dres, int nparts, const int* __restrict__ oob,
+                                double* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double sum = 0, mx = 0;
         for (int k = 0; k < nparts; ++k) { sum += dres[2 * k]; mx = fmax(mx, dres[2 * k + 1]); }
-        out[0] = sum; out[1] = mx;
+        out[0] = sum; out[1] = *oob ? 1.0 : 0.0; out[2] = mx;
     }
 }
 
 // An advection of a slab does not wait for its out-of-halo flag; the flag comes back with the next
-// reduction result or synchronisation and stays set until the handle is reset.
+// reduction result or synchronisation and stays set until the handle is reset or loaded.  The flag is part of
+// what the ranks add up, so every rank reports the failure at the same call (a rank that stopped alone would
+// leave the others waiting in their next exchange).
 int oob_status(fs3d_sim* s) {
-    if (s->nparts_global > 1 && *s->hoob) return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells)");
+    if (s->nparts_global > 1 && s->hres[1] > 0.0)
+        return set_err(s, FS_ESTATE, "a backtrace left the slab halo (|v|*dt > 2 cells) on this or another rank");
     return FS_OK;
 }
 
@@ -636,12 +694,13 @@ int queue_reduction(fs3d_sim* s, bool want_max) {
     // the halo traffic of the other stream (every rank issues the two in the same order)
     if (s->nranks > 1 && s->comm_red == s->comm) FS_TRY(join_halos(s));
     double* comb = s->dres + 2 * s->nlocal;
-    hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, comb);
+    hipLaunchKernelGGL(k_combine_parts, dim3(1), dim3(64), 0, s->stream, s->dres, s->nlocal, s->doob, comb);
     SIM_HIP(hipGetLastError());
     if (s->nranks > 1) {
-        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 1, ncclDouble, ncclSum, s->comm_red, s->stream), "ncclAllReduce"));
+        // the sum and the out-of-halo count travel together
+        FS_TRY(nccl_check(s, s->rccl->AllReduce(comb, comb, 2, ncclDouble, ncclSum, s->comm_red, s->stream), "ncclAllReduce"));
         if (want_max)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
-            FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 1, comb + 1, 1, ncclDouble, ncclMax, s->comm_red, s->stream), "ncclAllReduce"));
+            FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 2, comb + 2, 1, ncclDouble, ncclMax, s->comm_red, s->stream), "ncclAllReduce"));
     }
     SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     return FS_OK;
@@ -649,9 +708,12 @@ int queue_reduction(fs3d_sim* s, bool want_max) {
 
 int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
     FS_TRY(queue_reduction(s, mx != nullptr));
+    const auto t0 = std::chrono::steady_clock::now();
     FS_TRY(quiesce(s));
+    s->cstats.reduction_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++s->cstats.reductions;
     if (sum) *sum = s->hres[0];
-    if (mx) *mx = s->hres[1];
+    if (mx) *mx = s->hres[2];
     return oob_status(s);
 }
 
@@ -1556,13 +1618,12 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     SIM_HIP(hipEventCreateWithFlags(&s->ev_bnd, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
-    SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 3)));
+    SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 4)));
     SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 3, hipHostMallocDefault));
-    // the out-of-halo flag sits behind the combined pair, so that the copy of a reduction result brings it along
-    s->doob = reinterpret_cast<int*>(s->dres + 2 * s->nlocal + 2);
-    s->hoob = reinterpret_cast<int*>(s->hres + 2);
+    // the flag the advection kernels raise sits behind the combined record
+    s->doob = reinterpret_cast<int*>(s->dres + 2 * s->nlocal + 3);
     SIM_HIP(hipMemset(s->doob, 0, sizeof(double)));
-    *s->hoob = 0;
+    s->hres[0] = s->hres[1] = s->hres[2] = 0.0;
     if (nranks > 1) {
         s->rccl = Rccl::get(s->err);
         if (!s->rccl) return FS_ECOMM;
@@ -1571,7 +1632,11 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
         memcpy(&uid, id, sizeof uid);
         FS_TRY(nccl_check(s, s->rccl->CommInitRank(&s->comm, nranks, uid, rank), "ncclCommInitRank"));
         s->comm_red = s->comm;
-        if (s->rccl->CommSplit && !(getenv("FSAMD_ONE_COMMUNICATOR") && getenv("FSAMD_ONE_COMMUNICATOR")[0] == '1')) {
+        // One communicator by default: the reductions then queue behind the halo traffic (join_halos), which is the
+        // order every rank issues.  FSAMD_SPLIT_COMMUNICATOR=1 gives the reductions a copy of their own, so that
+        // they run beside the halo traffic of the other stream; two communicators with work in flight on one
+        // device is a pattern that needs a validated multi-GPU run first, hence opt-in.
+        if (s->rccl->CommSplit && getenv("FSAMD_SPLIT_COMMUNICATOR") && getenv("FSAMD_SPLIT_COMMUNICATOR")[0] == '1') {
             ncclComm_t copy = nullptr;   // same ranks, same order; every rank takes part (collective call)
             if (s->rccl->CommSplit(s->comm, 0, rank, &copy, nullptr) == ncclSuccess && copy) s->comm_red = copy;
         }
@@ -1715,6 +1780,7 @@ void fs3d_destroy(fs3d_sim* s) {
     (void)hipFree(s->dres);
     if (s->hres) (void)hipHostFree(s->hres);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& t : s->timed) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
     if (s->comm_stream) { (void)hipStreamSynchronize(s->comm_stream); (void)hipStreamDestroy(s->comm_stream); }
     if (s->ev_bnd) (void)hipEventDestroy(s->ev_bnd);
     if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
@@ -1736,7 +1802,7 @@ int fs3d_reset(fs3d_sim* s) {
     s->mg_backoff[0] = s->mg_backoff[1] = 0;
     s->mg_fails[0] = s->mg_fails[1] = 0;
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
-    *s->hoob = 0;
+    s->hres[1] = 0.0;
     s->stats = fs3d_stats{};
     s->halo_dirty = HALO_ALL;
     FS_TRY(quiesce(s));
@@ -1953,6 +2019,34 @@ int fs3d_time_sweeps(fs3d_sim* s, int n, double* ms) {
     return FS_OK;
 }
 
+int fs3d_time_advections(fs3d_sim* s, int n, double t_step, int reflected, double* ms) {
+    SIM_GUARD(s);
+    if (n < 1) return set_err(s, FS_EINVAL, "n must be >= 1");
+    FS_TRY(prepare(s, HALO_ALL));
+    const bool refl = reflected != 0;
+    if (refl) {   // any field will do as the unprojected one: the scratch velocity is a copy of the current one
+        if (s->cfg.advect_kernel != FS_ADVECT_TILED) return set_err(s, FS_ESTATE, "the reflected advection is the staged kernel's");
+        s->tilde_gen = -1;
+        for (Part& p : s->parts)
+            for (int k = 0; k < 3; ++k)
+                SIM_HIP(hipMemcpyAsync(p.tmp[k], p.f[s->curv][k], p.n * s->esz, hipMemcpyDeviceToDevice, s->stream));
+        s->halo_dirty &= ~HALO_TMP;
+    }
+    FS_TRY(join_halos(s));
+    SIM_HIP(hipEventRecord(s->ev[0], s->stream));
+    for (int i = 0; i < n; ++i) {
+        if (refl) FS_TRY(DISPATCH(s, advect, s, t_step, true, 0, false, true, nullptr));
+        else FS_TRY(DISPATCH(s, advect, s, t_step, false, 1, false, false, nullptr));
+    }
+    FS_TRY(join_halos(s));
+    SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+    SIM_HIP(hipEventSynchronize(s->ev[1]));
+    float t = 0;
+    SIM_HIP(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+    if (ms) *ms = t;
+    return FS_OK;
+}
+
 int fs3d_project(fs3d_sim* s, int* sweeps, double* metric) {
     SIM_GUARD(s);
     s->resid_dt = 1.0;
@@ -2059,7 +2153,11 @@ int fs3d_save(fs3d_sim* s, const char* path) {
     const int fd = open(path, O_WRONLY | O_CREAT, 0644);
     if (fd < 0) return set_err(s, FS_ESTATE, "cannot open the restart file for writing");
     int rc = FS_OK;
-    if (s->rank == 0) {
+    // the file has exactly the size of header + payload, whatever was at the path before (every rank sets the
+    // same size, so the order in which the ranks arrive does not matter)
+    const off_t total = (off_t)(sizeof(RestartHeader) + cells + 4 * cells * s->esz);
+    if (ftruncate(fd, total) != 0) rc = set_err(s, FS_ESTATE, "cannot size the restart file");
+    if (rc == FS_OK && s->rank == 0) {
         RestartHeader h{};
         memcpy(h.magic, "FSAMD3D", 8);
         h.version = 1; h.dtype = s->cfg.dtype; h.nx = s->nx; h.ny = s->ny; h.nz = s->nz;
@@ -2092,10 +2190,13 @@ int fs3d_load(fs3d_sim* s, const char* path) {
     if (fd < 0) return set_err(s, FS_ESTATE, "cannot open the restart file");
     RestartHeader h{};
     int rc = file_io(s, fd, false, &h, sizeof(h), 0);
+    const off_t fsize = lseek(fd, 0, SEEK_END);
     if (rc == FS_OK && (memcmp(h.magic, "FSAMD3D", 8) != 0 || h.version != 1))
         rc = set_err(s, FS_EINVAL, "not a restart file of this library");
     if (rc == FS_OK && (h.nx != s->nx || h.ny != s->ny || h.nz != s->nz || h.dtype != s->cfg.dtype))
         rc = set_err(s, FS_EINVAL, "the restart file has another grid size or element type");
+    if (rc == FS_OK && fsize != (off_t)(sizeof(RestartHeader) + cells + 4 * cells * s->esz))
+        rc = set_err(s, FS_EINVAL, "the restart file is incomplete or has trailing bytes");
     std::vector<char> buf(mine * s->esz);
     if (rc == FS_OK) rc = file_io(s, fd, false, buf.data(), mine, (off_t)(sizeof(RestartHeader) + plane * z0));
     if (rc == FS_OK) rc = fs3d_set_cell_types(s, (const uint8_t*)buf.data(), mine);
@@ -2111,6 +2212,10 @@ int fs3d_load(fs3d_sim* s, const char* path) {
     unpack_schedule(s, h.sched);
     s->stats = fs3d_stats{};
     s->stats.step = h.step; s->stats.time = h.time;
+    // a loaded state starts with a clean out-of-halo record, like a reset one
+    SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
+    s->hres[1] = 0.0;
+    FS_TRY(quiesce(s));
     return FS_OK;
 }
 
@@ -2129,10 +2234,30 @@ int fs3d_get_stats(fs3d_sim* s, fs3d_stats* out) {
     return FS_OK;
 }
 
+int fs3d_comm_timing(fs3d_sim* s, int on) {
+    SIM_GUARD(s);
+    FS_TRY(quiesce(s));
+    for (auto& t : s->timed) timed_resolve(s, t);
+    s->comm_timing = on != 0;
+    return FS_OK;
+}
+
+int fs3d_get_comm_stats(fs3d_sim* s, fs3d_comm_stats* out, int reset) {
+    SIM_GUARD(s);
+    if (!out) return set_err(s, FS_EINVAL, "null pointer");
+    FS_TRY(quiesce(s));
+    SIM_HIP(hipStreamSynchronize(s->comm_stream));
+    for (auto& t : s->timed) timed_resolve(s, t);
+    *out = s->cstats;
+    if (reset) s->cstats = fs3d_comm_stats{};
+    return FS_OK;
+}
+
 int fs3d_synchronize(fs3d_sim* s) {
     SIM_GUARD(s);
-    if (s->nparts_global > 1)
-        SIM_HIP(hipMemcpyAsync(s->hoob, s->doob, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    // with several ranks the out-of-halo flag is added up over the ranks, so that all of them return the same
+    // status: on a handle of fs3d_create_slab this call is collective
+    if (s->nparts_global > 1) FS_TRY(queue_reduction(s, false));
     FS_TRY(quiesce(s));
     return oob_status(s);
 }

@@ -228,6 +228,10 @@ int fs3d_sweeps(fs3d_sim *sim, int n);
  * two events on that stream; *ms receives the device time between them (the
  * reference times whole frames with std::chrono, main.cpp:502, :541-543).    */
 int fs3d_time_sweeps(fs3d_sim *sim, int n, double *ms);
+/* The same for the advection: n advections of length t_step back to back (reflected == 0: semi_lagrange of
+ * the current state, main.cpp:256-291; else the second half advection of the advection-reflection step,
+ * which carries the reflection of a copy of the current velocity), *ms = device time between the events.   */
+int fs3d_time_advections(fs3d_sim *sim, int n, double t_step, int reflected, double *ms);
 /* The projection loop of update() (main.cpp:105-111) under the configured
  * stopping rule; outputs may be NULL.                                       */
 int fs3d_project(fs3d_sim *sim, int *sweeps, double *metric);
@@ -249,7 +253,10 @@ int fs3d_get_stats(fs3d_sim *sim, fs3d_stats *out);
  * an advection whose backtrace needed a plane beyond the two halo planes
  * (|v| dt > 2 cells at a slab interface) is not waited for when it is queued:
  * this call, and any projection that evaluates its stopping metric, returns
- * FS_ESTATE for it, until fs3d_reset.                                        */
+ * FS_ESTATE for it, until fs3d_reset or fs3d_load.  The flag is added up over
+ * the ranks together with the reduced scalars, so every rank returns FS_ESTATE
+ * at the same call, whichever rank's backtrace left its halo; for that reason
+ * this call is collective on a handle of fs3d_create_slab with several ranks. */
 int fs3d_synchronize(fs3d_sim *sim);
 
 /* Diagnostics of the current state (the reference prints none; they are what shows
@@ -272,7 +279,11 @@ int fs3d_get_density_downsampled(fs3d_sim *sim, int factor, void *host, size_t c
  * type, step, time, the cell types and u, v, w, density of the whole grid to `path`
  * (every rank of a slab decomposition writes its planes into the same file);
  * fs3d_load reads them back into a handle of the same size and element type.  A run
- * continued from a file repeats the uninterrupted run bit for bit.                 */
+ * continued from a file repeats the uninterrupted run bit for bit.  fs3d_save sets the
+ * file to its exact size first (stale bytes of an older, larger file do not survive) and
+ * fs3d_load refuses a file of any other size; with several ranks the caller puts a
+ * barrier between fs3d_save and the first read of the file, since a rank returns when its
+ * own planes are written.                                                              */
 int fs3d_save(fs3d_sim *sim, const char *path);
 int fs3d_load(fs3d_sim *sim, const char *path);
 
@@ -306,6 +317,22 @@ int fs3d_create_slab(int nx, int ny, int nz_global, const fs3d_config *cfg, int 
                      const uint8_t id[FS_COMM_ID_BYTES], fs3d_sim **out);
 /* Owned plane range of this handle in global coordinates.                   */
 int fs3d_slab_range(const fs3d_sim *sim, int *z0, int *z1, int *halo);
+/* What the slab decomposition costs this rank (no counterpart in the reference, which times whole frames,
+ * main.cpp:502, :541-543): counts and bytes are always kept; the two device times need an event pair around
+ * every exchange and every wait and are kept only while fs3d_comm_timing(sim, 1) is in force.             */
+typedef struct fs3d_comm_stats {
+    int64_t exchanges;         /* halo exchanges queued (one grouped send/receive per neighbour each)        */
+    int64_t waits;             /* times the compute stream was made to wait for the exchange stream         */
+    int64_t reductions;        /* all-reduced scalar records fetched to the host (stopping rule, diagnostics) */
+    int64_t bytes_sent_lo;     /* bytes sent to the rank below / above (as many are received)                */
+    int64_t bytes_sent_hi;
+    double exchange_ms;        /* device time of the exchanges on the exchange stream                        */
+    double wait_ms;            /* device time the compute stream spent waiting for them: exposed communication */
+    double reduction_host_ms;  /* host wall time spent blocked on the reductions                             */
+} fs3d_comm_stats;
+int fs3d_comm_timing(fs3d_sim *sim, int on);
+/* reset != 0 zeroes the record after it is copied out */
+int fs3d_get_comm_stats(fs3d_sim *sim, fs3d_comm_stats *out, int reset);
 
 /* ------------------------------------------------------------------------
  * The 2D fp64 smoke solver: class FluidSim of 3_fluid/FluidSim.h:11-303 and

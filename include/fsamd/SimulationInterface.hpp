@@ -3,6 +3,13 @@
 // meaning, with the libigl viewer type only forward-declared so that the
 // adapters build without libigl, GLFW or OpenGL.
 //
+// One member of the reference's class is left out on purpose: getObjects() / m_objects
+// (Simulation.h:64, :73), a std::vector<RigidObject>.  RigidObject is a libigl/Eigen mesh
+// type that cannot be declared without those libraries, and no fluid simulation of the
+// reference ever fills the list (3_fluid/FluidSim.h never touches m_objects).  Over the
+// reference's own base class the adapters inherit the (empty) list unchanged;
+// tests/cpp/real_interface_check.cpp compiles exactly that.
+//
 // A caller that has the reference tree uses the reference's own `Simulation`
 // as the adapter's base class instead (fsamd::FluidSim3DSimulation<Simulation>,
 // the template takes the base as its parameter); this mirror is what the tests

@@ -21,12 +21,38 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
 
 
-def _lib(dtype):
-    name = {np.float32: "f32", np.float64: "f64"}[dtype]
+_NATIVE_PATH = None
+
+
+def build_native():
+    """The fp32 oracle once more with -O3 -march=native (same source, still no fused multiply-add), for timing it as
+    the CPU baseline on the machine it is built on: compiled into a temporary directory at run time, never shipped
+    (-march=native code may not run on another machine).  Returns False if that build is not possible here."""
+    global _NATIVE_PATH
+    if _NATIVE_PATH:
+        return True
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="fsamd_oracle_"), "libfluid3d_oracle_f32_native.so")
+    cmd = [os.environ.get("CC", "gcc"), "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-shared", "-fopenmp",
+           "-DREAL=float", "-o", out, os.path.join(_HERE, "fluid3d_oracle.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _NATIVE_PATH = out
+    return True
+
+
+def _lib(dtype, native=False):
+    name = {np.float32: "f32", np.float64: "f64"}[dtype] + ("_native" if native else "")
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(_HERE, f"libfluid3d_oracle_{name}.so")
-    if not os.path.exists(path):
+    if native:
+        if dtype is not np.float32 or not build_native():
+            raise RuntimeError("no native build of the oracle")
+        path = _NATIVE_PATH
+    elif not os.path.exists(path):
         build()
     lib = C.CDLL(path)
     real = C.c_float if dtype is np.float32 else C.c_double
@@ -95,9 +121,9 @@ def _view(arr, owner):
 class Oracle3D:
     """The reference's 3D FluidSim (advection-reflection/main.cpp:21-442), restated on the CPU."""
 
-    def __init__(self, nx, ny, nz, dtype=np.float32):
+    def __init__(self, nx, ny, nz, dtype=np.float32, native=False):
         self.dtype = dtype
-        self.lib = _lib(dtype)
+        self.lib = _lib(dtype, native)
         self.nx, self.ny, self.nz = nx, ny, nz
         self.h = self.lib.o3_create(nx, ny, nz)
         self.n = nx * ny * nz

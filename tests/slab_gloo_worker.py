@@ -1,6 +1,10 @@
 """Worker of tests/test_slab_gloo.py: one rank = one z-slab, the oracle does the arithmetic, the
-exchange schedule is the library's (one interface plane of w per half-sweep, merged by parity;
-per-rank residual sums added across ranks)."""
+exchange schedule is the library's.  Mode `two_pass`: one interface plane of w per half-sweep, merged by
+parity.  Mode `one_pass` (the production schedule of the one-pass sweep): per full sweep a slab applies the
+first colour to its planes and to the two ghost planes below and one above, the second colour to its planes
+and one ghost plane below (its halo planes go stale, its owned planes come out exact), and then hands its
+two outermost owned planes of u, v and w to each neighbour's halo.  In both modes the per-rank residual sums
+are added across ranks."""
 import os
 import sys
 
@@ -20,45 +24,71 @@ from tests.util3d import random_cells, random_field  # noqa: E402
 
 def main():
     nx, ny, nz, sweeps = (int(v) for v in sys.argv[1:5])
+    mode = sys.argv[5] if len(sys.argv) > 5 else "two_pass"
     rank, world = fdist.init_control_plane("gloo")
     lay = SlabLayout(nz, world, rank)
     rng = np.random.default_rng(1234)          # every rank draws the same global state
     cells = random_cells((nz, ny, nx), rng)
     fields = [random_field((nz, ny, nx), rng, np.float32) for _ in range(4)]
 
-    o = Oracle3D(nx, ny, lay.nzl)
+    # The library keeps a flag byte per cell that says which neighbours are Fluid, taken from the owner of every
+    # plane; the oracle looks the neighbours' cell types up instead, so the slab gets one more plane of cell types
+    # either side than the library holds (the visit of the outermost halo plane reads the type below it).
+    pad = 1
+    nzl, gz0 = lay.nzl + 2 * pad, lay.gz0 - pad
+    zb, ze = lay.zb + pad, lay.ze + pad
+    o = Oracle3D(nx, ny, nzl)
     o.cells[...] = OBJECT
-    for lz in range(lay.nzl):
-        gz = lz + lay.gz0
+    for lz in range(nzl):
+        gz = lz + gz0
         if 0 <= gz < nz:
             o.cells[lz] = cells[gz]
-            for k in range(4):
-                o.field(k)[lz] = fields[k][gz]
+            if pad <= lz < nzl - pad:
+                for k in range(4):
+                    o.field(k)[lz] = fields[k][gz]
 
     parity = (np.add.outer(np.arange(ny), np.arange(nx)) & 1)    # (x + y) & 1
 
     def exchange(colour):
-        for upper, peer, lz in ((True, rank - 1, lay.lz_lo_interface), (False, rank + 1, lay.lz_hi_interface)):
+        for upper, peer, lz in ((True, rank - 1, lay.lz_lo_interface + pad), (False, rank + 1, lay.lz_hi_interface + pad)):
             if peer < 0 or peer >= world:
                 continue
             theirs = fdist.exchange_plane(np.array(o.w[lz]), peer)
-            take = ((parity + lz + lay.gz0) & 1) == take_parity(colour, upper)
+            take = ((parity + lz + gz0) & 1) == take_parity(colour, upper)
             o.w[lz][take] = theirs[take]
 
+    def exchange_two_planes():
+        # my two outermost owned planes of u, v, w go into the neighbour's halo, theirs into mine
+        # (fs3d.hip, one_pass_driver: one grouped send/receive per neighbour and sweep)
+        H, own = lay.halo, lay.z1 - lay.z0
+        for peer, mine_at, halo_at in ((rank - 1, pad + H, pad), (rank + 1, pad + own, pad + H + own)):
+            if peer < 0 or peer >= world:
+                continue
+            mine = np.stack([np.array(o.field(k)[mine_at:mine_at + H]) for k in range(3)])
+            theirs = fdist.exchange_plane(mine, peer)
+            for k in range(3):
+                o.field(k)[halo_at:halo_at + H] = theirs[k]
+
     for _ in range(sweeps):
+        if mode == "one_pass":
+            # the plane ranges of the kernel (fs3d.hip, fused_ranges): first colour on [zb-2, ze+1), second on [zb-1, ze)
+            o.rb_halfsweep_range(0, zb - (2 if lay.has_lo else 0), ze + (1 if lay.has_hi else 0), gz0)
+            o.rb_halfsweep_range(1, zb - (1 if lay.has_lo else 0), ze, gz0)
+            exchange_two_planes()
+            continue
         for colour in (0, 1):
-            o.rb_halfsweep_range(colour, lay.zb, lay.ze, lay.gz0)
+            o.rb_halfsweep_range(colour, zb, ze, gz0)
             exchange(colour)
 
     # residual: per-rank sum over the owned interior planes, added across ranks
     u, v, w = o.u, o.v, o.w
-    sl = slice(lay.zb, lay.ze)
+    sl = slice(zb, ze)
     div = (u[sl, 1:-1, 2:] - u[sl, 1:-1, 1:-1]) + (v[sl, 2:, 1:-1] - v[sl, 1:-1, 1:-1]) + \
-          (w[lay.zb + 1:lay.ze + 1, 1:-1, 1:-1] - w[sl, 1:-1, 1:-1])
+          (w[zb + 1:ze + 1, 1:-1, 1:-1] - w[sl, 1:-1, 1:-1])
     total = fdist.sum_over_ranks(float((div.astype(np.float64) ** 2).sum()))
     slowest = fdist.max_over_ranks(rank + 1.0)
 
-    own = slice(lay.halo, lay.halo + lay.z1 - lay.z0)
+    own = slice(pad + lay.halo, pad + lay.halo + lay.z1 - lay.z0)
     gathered = [fdist.gather_planes(np.array(o.field(k)[own])) for k in range(3)]
     token = fdist.broadcast_bytes(b"id-from-rank-0" if rank == 0 else None)
     assert token == b"id-from-rank-0"

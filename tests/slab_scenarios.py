@@ -106,6 +106,37 @@ def vortex_ring_multigrid(fs, **kw):
     return vortex_ring(fs, check_every=-1, steps=5, solver=1, **kw)
 
 
+def oob_one_rank(fs, rank=0, nranks=1, comm_id=None):
+    """A backtrace that leaves the two halo planes on the upper slab only (|w| dt = 4 cells just above the
+    interface): the advection does not wait for its flag, and the next call that does (a residual, then
+    fs3d_synchronize) must fail on EVERY rank, not only on the one whose kernel raised it.  A single domain has
+    no halo to leave: it returns the record every rank must produce."""
+    if nranks == 1:
+        return {"residual_raised": np.float64(1), "synchronize_raised": np.float64(1), "after_reset_ok": np.float64(1)}
+    nx, ny, nz = 24, 16, 12 * nranks
+    g = fs.FluidSim3D(nx, ny, nz, rank=rank, nranks=nranks, comm_id=comm_id, device=0, stop_mode=fs.STOP_FIXED, max_iters=1)
+    w = np.zeros((nz, ny, nx), np.float32)
+    w[nz - 11, 4:12, 4:20] = 200.0          # the second owned plane of the last slab; 200 * 0.02 = 4 cells down
+    g.set_field(2, w[g.z0:g.z1])
+    rec = {}
+    g.semi_lagrange(0.02)                   # queued; nobody has looked at the flag yet
+    for name, call in (("residual", g.residual), ("synchronize", g.synchronize)):
+        try:
+            call()
+            rec[f"{name}_raised"] = np.float64(0)
+        except fs.FluidSimError as e:
+            assert "halo" in str(e)
+            rec[f"{name}_raised"] = np.float64(1)
+    g.reset()                               # forgets the flag on every rank
+    g.semi_lagrange(0.02)
+    g.synchronize()
+    rec["after_reset_ok"] = np.float64(1)
+    g.close()
+    return rec
+
+
+SPECIAL = {"oob_one_rank": oob_one_rank}
+
 SCENARIOS = {f.__name__: f for f in (steps_l1, steps_two_pass, steps_residual, steps_maccormack, vortex_ring,
                                      vortex_ring_deferred, vortex_ring_multigrid)}
 
@@ -145,4 +176,4 @@ def run(fs, name, rank=0, nranks=1, comm_id=None, comm_ids=None):
     if name.startswith("random:"):       # random:<seed>:<world>:<count>
         seed, world, count = map(int, name.split(":")[1:])
         return random_configurations(fs, seed, world, count, rank=rank, nranks=nranks, comm_ids=comm_ids)
-    return SCENARIOS[name](fs, rank=rank, nranks=nranks, comm_id=comm_id)
+    return (SPECIAL.get(name) or SCENARIOS[name])(fs, rank=rank, nranks=nranks, comm_id=comm_id)

@@ -15,6 +15,13 @@ def test_adapter_builds():
     assert os.path.exists(os.path.join(CPP, "adapter_main"))
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include"), reason="needs the reference tree (build container only)")
+def test_adapters_compile_against_the_reference_s_own_simulation_header():
+    # FluidSim3DSimulation<Simulation> and FluidSim2DSimulation<Simulation> over include/Simulation.h:11-78 itself
+    # (libigl viewer type, RigidObject list and all), driven through a Simulation* like Simulator::runSimThread
+    subprocess.check_call(["make", "-s", "-C", CPP, "real_interface_check"])
+
+
 @pytest.mark.gpu
 def test_adapter_reproduces_oracle(tmp_path):
     from oracle.oracle3d import Oracle3D

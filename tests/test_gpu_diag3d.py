@@ -87,3 +87,16 @@ def test_restart_file_continues_bit_for_bit(fsamd, tmp_path, slabs):
     c = fsamd.FluidSim3D(n + 2, n, n)
     with pytest.raises(fsamd.FluidSimError, match="grid size"):
         c.load(path)
+    # a truncated file, and one with bytes left over from an older, larger file, are refused; saving over the
+    # latter sets the exact size again
+    with open(path, "r+b") as f:
+        f.truncate(len(raw) - 5)
+    with pytest.raises(fsamd.FluidSimError, match="incomplete"):
+        b.load(path)
+    with open(path, "wb") as f:
+        f.write(raw + b"stale tail")
+    with pytest.raises(fsamd.FluidSimError, match="trailing"):
+        b.load(path)
+    b.save(path)
+    assert os.path.getsize(path) == len(raw)
+    b.load(path)

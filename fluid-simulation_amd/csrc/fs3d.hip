@@ -654,13 +654,14 @@ int sweep_once(fs3d_sim* s) {
         FS_TRY(launch_halfsweep<T>(s, 0));
         return launch_halfsweep<T>(s, 1);
     }
-    // lexicographic order as hyperplane wavefronts (single part only)
+    // the reference's lexicographic order: one launch per diagonal of 16^3-cell blocks (single part only)
     Part& p = s->parts[0];
-    const T omega = (T)s->cfg.omega;
-    dim3 b(64, 4, 1), g(div_up(s->ny - 2, 64), div_up(s->nz - 2, 4), 1);
-    for (int k = 3; k <= (s->nx - 2) + (s->ny - 2) + (s->nz - 2); ++k)
-        hipLaunchKernelGGL(k_lexi_hyperplane<T>, g, b, 0, s->stream, p.g, F<T>(p, s->curv, 0), F<T>(p, s->curv, 1),
-                           F<T>(p, s->curv, 2), p.flags, k, omega);
+    using C = LexiBlock<T>;
+    SIM_HIP(allow_lds(s, (const void*)k_lexi_blocks<T>, C::lds_bytes()));
+    const int nbx = div_up(s->nx - 2, C::LB), nby = div_up(s->ny - 2, C::LB), nbz = div_up(s->nz - 2, C::LB);
+    for (int K = 0; K <= nbx + nby + nbz - 3; ++K)
+        hipLaunchKernelGGL(k_lexi_blocks<T>, dim3(nby, nbz, 1), dim3(256), C::lds_bytes(), s->stream, p.g, F<T>(p, s->curv, 0),
+                           F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), p.flags, K, nbx, (T)s->cfg.omega);
     SIM_HIP(hipGetLastError());
     return FS_OK;
 }

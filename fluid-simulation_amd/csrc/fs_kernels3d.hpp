@@ -123,55 +123,164 @@ __global__ void k_merge_w_plane(Grid g, T* __restrict__ w, const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// Projection, the reference's lexicographic order (main.cpp:235) executed as
-// hyperplane wavefronts: all cells with x+y+z == k are independent of each
-// other, their low neighbours lie on plane k-1 and their high neighbours on
-// k+1, so running k upwards reproduces the serial sweep bit for bit.
+// Projection, the reference's lexicographic order (main.cpp:235), bit for bit.
+//
+// A visit reads and writes only the visited cell's own six faces, so two visits
+// commute unless the cells share a face, and the serial sweep is fixed by one
+// rule: of two face neighbours the one with the smaller index is visited first.
+// Every schedule that keeps that rule gives the serial result.  Here the
+// interior is cut into blocks of LB^3 cells.  Blocks on a diagonal
+// bi + bj + bk = K share no face (face neighbours differ by one in exactly one
+// block index), their low neighbours lie on diagonal K - 1 and their high
+// neighbours on K + 1: one launch per diagonal, K ascending.  Inside a block
+// the same argument holds for cells: one workgroup keeps the block's faces in
+// LDS and walks the local diagonals lx + ly + lz = k with a barrier between
+// them.  A sweep is nbx + nby + nbz - 2 launches instead of one per cell
+// diagonal of the whole grid.
 template <typename T>
-__global__ void k_lexi_hyperplane(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w,
-                                  const uint8_t* __restrict__ flags, int k, T omega) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    const int z = blockIdx.y * blockDim.y + threadIdx.y + 1;
-    if (y > g.ny - 2 || z > g.nzl - 2) return;
-    const int x = k - y - z;
-    if (x < 1 || x > g.nx - 2) return;
-    const int64_t i = gidx(g, x, y, z);
-    const uint32_t fl = flags[i];
-    if (!relaxes(fl)) return;
-    const T dd = cell_dd(g, u, v, w, i, fl, omega);
-    const bool self = fl & FL_SELF_FLUID;
-    if ((fl & FL_XM) && self) u[i] += dd;
-    if (fl & FL_XP) u[i + 1] -= dd;
-    if ((fl & FL_YM) && self) v[i] += dd;
-    if (fl & FL_YP) v[i + g.sy] -= dd;
-    if ((fl & FL_ZM) && self) w[i] += dd;
-    if (fl & FL_ZP) w[i + g.sz] -= dd;
+struct LexiBlock {
+    static constexpr int LB = 16;              // cells per block edge; LB * LB threads
+    static constexpr int PU = LB + 2;          // row pitch of the u tile (LB + 1 faces per row; even pitch - 1 = odd stride)
+    static constexpr int NU = PU * LB * LB;    // u[lz][ly][0..LB]
+    static constexpr int NV = LB * (LB + 1) * LB;   // v[lz][0..LB][lx]
+    static constexpr int NW = LB * LB * (LB + 1);   // w[0..LB][ly][lx]
+    static constexpr int NF = LB * LB * LB;         // flag bytes of the block's cells
+    static constexpr size_t lds_bytes() { return (size_t)(NU + NV + NW) * sizeof(T) + NF; }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_lexi_blocks(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w, const uint8_t* __restrict__ flags, int K,
+              int nbx, T omega) {
+    using C = LexiBlock<T>;
+    constexpr int LB = C::LB, PU = C::PU;
+    const int bj = blockIdx.x, bk = blockIdx.y, bi = K - bj - bk;
+    if (bi < 0 || bi >= nbx) return;   // uniform over the workgroup
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* tu = reinterpret_cast<T*>(lds_raw);
+    T* tv = tu + C::NU;
+    T* tw = tv + C::NV;
+    uint8_t* tf = reinterpret_cast<uint8_t*>(tw + C::NW);
+    const int x0 = 1 + bi * LB, y0 = 1 + bj * LB, z0 = 1 + bk * LB;
+    // cells of this block: the part of [x0, x0+LB) x ... that is interior
+    const int ex = min(LB, g.nx - 1 - x0), ey = min(LB, g.ny - 1 - y0), ez = min(LB, g.nzl - 1 - z0);
+    const int tid = threadIdx.x;
+    // Faces of the block's cells: u[0..ex] x ey x ez, v: ex x [0..ey] x ez, w: ex x ey x [0..ez]; all inside the grid
+    // because the cells are interior.  A thread moves the column (cx, cy, 0..LB-1) of every array plus one element
+    // of each array's extra layer (the high faces of the last cells); all its loads are issued before the first
+    // is used, so the tile arrives in about one memory round trip.
+    const int cx = tid % LB, cy = tid / LB;
+    {
+        T ru[LB], rv[LB], rw[LB], xu = 0, xv = 0, xw = 0;
+        uint8_t rf[LB];
+        const bool col = cx < ex && cy < ey;
+#pragma unroll
+        for (int lz = 0; lz < LB; ++lz) {
+            const bool in = col && lz < ez;
+            const int64_t i = in ? gidx(g, x0 + cx, y0 + cy, z0 + lz) : 0;
+            ru[lz] = in ? u[i] : (T)0; rv[lz] = in ? v[i] : (T)0; rw[lz] = in ? w[i] : (T)0;
+            rf[lz] = in ? flags[i] : (uint8_t)FL_SELF_OBJECT;
+        }
+        // extra layers: u at lx = ex for (ly, lz) = (cx, cy); v at ly = ey for (lx, lz) = (cx, cy); w at lz = ez for (lx, ly)
+        if (cx < ey && cy < ez) xu = u[gidx(g, x0 + ex, y0 + cx, z0 + cy)];
+        if (cx < ex && cy < ez) xv = v[gidx(g, x0 + cx, y0 + ey, z0 + cy)];
+        if (cx < ex && cy < ey) xw = w[gidx(g, x0 + cx, y0 + cy, z0 + ez)];
+#pragma unroll
+        for (int lz = 0; lz < LB; ++lz) {
+            tu[(lz * LB + cy) * PU + cx] = ru[lz];
+            tv[(lz * (LB + 1) + cy) * LB + cx] = rv[lz];
+            tw[(lz * LB + cy) * LB + cx] = rw[lz];
+            tf[(lz * LB + cy) * LB + cx] = rf[lz];
+        }
+        if (cx < ey && cy < ez) tu[(cy * LB + cx) * PU + ex] = xu;
+        if (cx < ex && cy < ez) tv[(cy * (LB + 1) + ey) * LB + cx] = xv;
+        if (cx < ex && cy < ey) tw[(ez * LB + cy) * LB + cx] = xw;
+    }
+    const int ly = tid % LB, lz = tid / LB;
+    const bool row = ly < ey && lz < ez;
+    __syncthreads();
+    for (int k = 0; k <= ex + ey + ez - 3; ++k) {
+        const int lx = k - ly - lz;
+        if (row && lx >= 0 && lx < ex) {
+            const uint32_t fl = tf[(lz * LB + ly) * LB + lx];
+            if (relaxes(fl)) {
+                T* pu = tu + (lz * LB + ly) * PU + lx;
+                T* pv = tv + (lz * (LB + 1) + ly) * LB + lx;
+                T* pw = tw + (lz * LB + ly) * LB + lx;
+                // main.cpp:217-225
+                const T div = (pu[1] - pu[0]) + (pv[LB] - pv[0]) + (pw[LB * LB] - pw[0]);
+                T dd = div / (T)__popc(fl & FL_NBR);
+                if (omega != (T)1) dd = omega * dd;
+                const bool self = fl & FL_SELF_FLUID;
+                if ((fl & FL_XM) && self) pu[0] += dd;      // main.cpp:227-232
+                if (fl & FL_XP) pu[1] -= dd;
+                if ((fl & FL_YM) && self) pv[0] += dd;
+                if (fl & FL_YP) pv[LB] -= dd;
+                if ((fl & FL_ZM) && self) pw[0] += dd;
+                if (fl & FL_ZP) pw[LB * LB] -= dd;
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const bool col = cx < ex && cy < ey;
+#pragma unroll
+        for (int lz2 = 0; lz2 < LB; ++lz2) {
+            if (col && lz2 < ez) {
+                const int64_t i = gidx(g, x0 + cx, y0 + cy, z0 + lz2);
+                u[i] = tu[(lz2 * LB + cy) * PU + cx];
+                v[i] = tv[(lz2 * (LB + 1) + cy) * LB + cx];
+                w[i] = tw[(lz2 * LB + cy) * LB + cx];
+            }
+        }
+        if (cx < ey && cy < ez) u[gidx(g, x0 + ex, y0 + cx, z0 + cy)] = tu[(cy * LB + cx) * PU + ex];
+        if (cx < ex && cy < ez) v[gidx(g, x0 + cx, y0 + ey, z0 + cy)] = tv[(cy * (LB + 1) + ey) * LB + cx];
+        if (cx < ex && cy < ey) w[gidx(g, x0 + cx, y0 + cy, z0 + ez)] = tw[(ez * LB + cy) * LB + cx];
+    }
 }
 
 // The reference sums the change in one scalar of the working precision, in
 // ascending cell order (main.cpp:243-249).  One wave reproduces that order:
-// the lanes fetch 64 consecutive cells, lane order is cell order, and the
-// running sum is carried through the lanes serially.
+// the lanes fetch 64 consecutive cells of an interior row, lane order is cell
+// order, and every lane adds the 192 values of the chunk in that order (lane
+// values read one by one into scalar registers), so the running sum is a chain
+// of dependent additions as in the reference.
+template <typename T>
+__device__ __forceinline__ T lane_value(T v, int l) {
+    if constexpr (sizeof(T) == 4) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    } else {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+}
+
 template <typename T>
 __global__ void k_change_serial(Grid g, const T* __restrict__ au, const T* __restrict__ av,
                                 const T* __restrict__ aw, const T* __restrict__ bu, const T* __restrict__ bv,
                                 const T* __restrict__ bw, double* __restrict__ out) {
     const int lane = threadIdx.x;
-    const int64_t n = (int64_t)g.nx * g.ny * g.nzl;
     T acc = 0;
-    for (int64_t base = 0; base < n; base += 64) {
-        const int64_t i = base + lane;
-        T a = 0, b = 0, c = 0;
-        if (i < n) {
-            const int x = (int)(i % g.nx), y = (int)((i / g.nx) % g.ny), z = (int)(i / g.sz);
-            if (x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && z > 0 && z < g.nzl - 1) {
-                a = fabs(au[i] - bu[i]); b = fabs(av[i] - bv[i]); c = fabs(aw[i] - bw[i]);
+    // interior cells in ascending index order: planes, rows, then x; cells outside the interior add nothing in the
+    // reference, and adding +0 here for the lanes beyond the end of a row changes no bit (the sum is never -0)
+    for (int z = 1; z < g.nzl - 1; ++z)
+        for (int y = 1; y < g.ny - 1; ++y) {
+            const int64_t row = gidx(g, 0, y, z);
+            for (int xb = 1; xb < g.nx - 1; xb += 64) {
+                const int x = xb + lane;
+                T a = 0, b = 0, c = 0;
+                if (x < g.nx - 1) {
+                    const int64_t i = row + x;
+                    a = fabs(au[i] - bu[i]); b = fabs(av[i] - bv[i]); c = fabs(aw[i] - bw[i]);
+                }
+#pragma unroll
+                for (int l = 0; l < 64; ++l) {
+                    acc += lane_value(a, l); acc += lane_value(b, l); acc += lane_value(c, l);
+                }
             }
         }
-        for (int l = 0; l < 64; ++l) {
-            acc += __shfl(a, l, 64); acc += __shfl(b, l, 64); acc += __shfl(c, l, 64);
-        }
-    }
     if (lane == 0) out[0] = (double)acc;
 }
 

@@ -54,8 +54,9 @@ enum { FS_FIELD_U = 0, FS_FIELD_V = 1, FS_FIELD_W = 2, FS_FIELD_DENSITY = 3, FS_
 enum {
     FS_ORDER_RED_BLACK = 0,     /* two half-sweeps, colour (x+y+z)&1 = 0 then 1          */
     FS_ORDER_LEXICOGRAPHIC = 1  /* the reference's order (main.cpp:235), run as
-                                   hyperplane wavefronts x+y+z = k; bit-identical
-                                   to the serial sweep, slow, for parity runs   */
+                                   diagonals of 16^3-cell blocks, one launch each;
+                                   bit-identical to the serial sweep, an order of
+                                   magnitude slower than red-black: for parity runs */
 };
 
 /* stopping rule of the projection loop */

@@ -33,6 +33,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include "fs_sweep_rows.hpp"
+#include "fs_sweep_rows2.hpp"
 #include "fs_advect_tiled.hpp"
 #include "fs_diag3d.hpp"
 #include "fs_mg3d.hpp"
@@ -647,6 +648,82 @@ int launch_one_pass_sweep(fs3d_sim* s) {
     return launch_fused_sweep<T>(s);
 }
 
+// Two sweeps in one pass over HBM (fs_sweep_rows2.hpp): single domain, even nx, the register-resident kernel.
+bool pairs_possible(const fs3d_sim* s) {
+    static const bool off = getenv("FSAMD_NO_SWEEP_PAIRS") && getenv("FSAMD_NO_SWEEP_PAIRS")[0] == '1';
+    return !off && s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel == FS_SWEEP_FUSED && s->nx % 2 == 0 &&
+           s->nparts_global == 1;
+}
+
+// One launch of the two-sweep kernel over `ntx` tiles of a row starting at column xbase.
+template <typename T, int NSEG, int CP>
+int launch_rows2_tiles(fs3d_sim* s, int ntx, int xbase, int xedges, int cv, int ov) {
+    using C = Rows2Cfg<T, NSEG, CP>;
+    auto kern = k_rb_rows2<T, NSEG, CP>;
+    SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
+    Part& p = s->parts[0];
+    const int rows = std::min(C::RY, s->ny);
+    const int nty = s->ny <= rows ? 1 : div_up(s->ny - 2 * C::S, rows - 2 * C::S);
+    // z-chunks: rounds of workgroups over the CUs (one workgroup of 16 waves per CU) x planes a workgroup marches
+    // through (its chunk, the eight planes of overlap and the pipeline)
+    int best_c = 1;
+    double best = 1e300;
+    for (int c = 1; c <= std::max(1, p.g.nzl / 8); ++c) {
+        const int zc = div_up(p.g.nzl, c);
+        const double cost = (double)div_up(ntx * nty * div_up(p.g.nzl, zc), s->num_cus) * (zc + 12);
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    const int zchunk = div_up(p.g.nzl, best_c), zgroups = div_up(p.g.nzl, zchunk);
+    dim3 b(64, rows, 1), g(ntx * nty * zgroups, 1, 1);
+    hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, zchunk, ntx, nty, rows, xbase, xedges);
+    return FS_OK;
+}
+
+// Tiles of W columns overlap by 8, so a row of nx columns takes ceil((nx - 8) / (W - 8)) of them; where the last of
+// these would hold few columns (nx = 512 is two tiles of 256 and sixteen columns) it goes to a launch of the narrow
+// variant instead, which marches through half the lanes.
+template <typename T, int NSEG, int CP>
+int launch_rows2(fs3d_sim* s) {
+    using C = Rows2Cfg<T, NSEG, CP>;
+    if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
+    const int cv = s->curv, ov = s->curv ^ 1;
+    const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
+    const int last_origin = (ntx - 1) * (C::W - 2 * C::S), last_cols = s->nx - last_origin;
+    if (ntx >= 2 && C::W > 128 && last_cols <= 128) {
+        FS_TRY((launch_rows2_tiles<T, NSEG, CP>(s, ntx - 1, 0, 1, cv, ov)));
+        FS_TRY((launch_rows2_tiles<T, 1, 1>(s, 1, last_origin, 2, cv, ov)));
+    } else {
+        FS_TRY((launch_rows2_tiles<T, NSEG, CP>(s, ntx, 0, 3, cv, ov)));
+    }
+    SIM_HIP(hipGetLastError());
+    s->curv ^= 1;
+    return FS_OK;
+}
+
+// Two sweeps; the caller has checked pairs_possible().
+template <typename T>
+int sweep_pair(fs3d_sim* s) {
+    if constexpr (sizeof(T) == 8) return launch_rows2<T, 1, 1>(s);
+    else {
+        if (s->nx % 4 == 0) return launch_rows2<T, 1, 2>(s);
+        return launch_rows2<T, 1, 1>(s);
+    }
+}
+
+template <typename T> int sweep_once(fs3d_sim* s);
+
+// n sweeps without any evaluation, two per pass where that is possible.
+template <typename T>
+int sweeps_n(fs3d_sim* s, int n) {
+    const bool pairs = pairs_possible(s);
+    while (n > 0) {
+        if (pairs && n >= 2) { FS_TRY(sweep_pair<T>(s)); n -= 2; }
+        else { FS_TRY(sweep_once<T>(s)); n -= 1; }
+    }
+    return FS_OK;
+}
+
 template <typename T>
 int sweep_once(fs3d_sim* s) {
     if (s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel != FS_SWEEP_TWO_PASS) return launch_one_pass_sweep<T>(s);
@@ -917,7 +994,7 @@ int mg_vcycle(fs3d_sim* s) {
         explicit OmegaOne(fs3d_sim* sim) : s(sim), saved(sim->cfg.omega) { s->cfg.omega = 1.0; }
         ~OmegaOne() { s->cfg.omega = saved; }
     } plain(s);
-    for (int k = 0; k < kMgNu1; ++k) FS_TRY(sweep_once<T>(s));
+    FS_TRY(sweeps_n<T>(s, kMgNu1));
     if (slabs) {   // the residual of a slab's top plane reads w of its first halo plane
         halos_after_sweeps(s);
         FS_TRY(refresh_halos(s, HALO_VEL));
@@ -945,8 +1022,7 @@ int mg_vcycle(fs3d_sim* s) {
         s->halo_dirty |= HALO_VEL;
         FS_TRY(refresh_halos(s, HALO_VEL, one_pass));
     }
-    for (int k = 0; k < kMgNu2; ++k) FS_TRY(sweep_once<T>(s));
-    return FS_OK;
+    return sweeps_n<T>(s, kMgNu2);
 }
 
 // One sweep with the reference's change metric (main.cpp:189-254).
@@ -996,8 +1072,9 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
     int next_check = check_after(resume_from);
     int it = resume_from;
     double metric = 0;
+    const bool pairs = pairs_possible(s);
     if (unchecked > 0) {
-        for (int k = 0; k < unchecked; ++k) FS_TRY(sweep_once<T>(s));
+        FS_TRY(sweeps_n<T>(s, unchecked));
         s->stats.sweeps = unchecked;
         s->stats.sweeps_step += unchecked;
         halos_after_sweeps(s);
@@ -1045,13 +1122,22 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
             *deferred = true;
             break;
         }
-        const bool check = (adaptive ? it + 1 == next_check : ((it + 1) % every == 0)) || (it + 1 >= c.max_iters);
-        if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
-            FS_TRY(sweep_with_change<T>(s, &metric));
+        auto is_check = [&](int n) { return (adaptive ? n == next_check : (n % every == 0)) || n >= c.max_iters; };
+        bool check = is_check(it + 1);
+        // two sweeps in one pass where the first of them is not evaluated (and, for the change of one sweep, the
+        // second is not either: that metric needs the field one sweep back)
+        if (pairs && !check && it + 2 <= c.max_iters && !(c.stop_mode == FS_STOP_L1_CHANGE && is_check(it + 2))) {
+            FS_TRY(sweep_pair<T>(s));
+            it += 2;
+            check = is_check(it);
         } else {
-            FS_TRY(sweep_once<T>(s));
+            if (c.stop_mode == FS_STOP_L1_CHANGE && check) {
+                FS_TRY(sweep_with_change<T>(s, &metric));
+            } else {
+                FS_TRY(sweep_once<T>(s));
+            }
+            ++it;
         }
-        ++it;
         if (check) next_check = check_after(it);
         if (c.stop_mode == FS_STOP_L1_CHANGE && check && !(metric > c.tol)) break;
         if (c.stop_mode == FS_STOP_L2_RESIDUAL && check) {
@@ -1099,7 +1185,8 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
     }
     auto go = [&](auto kern, size_t lds) -> int {
         SIM_HIP(allow_lds(s, (const void*)kern, lds));
-        const int tiles = div_up(s->nx, 64) * div_up(s->ny, 8);
+        constexpr int TY = AdvTile<T, false>::TY;
+        const int tiles = div_up(s->nx, 64) * div_up(s->ny, TY);
         // workgroups a CU holds at once: limited by LDS (160 KiB) and, at 72 registers, to 3 x 8 waves
         const int per_cu = std::max(1, std::min(3, (int)((size_t)160 * 1024 / lds)));
         int zchunk, zlen, zgroups;
@@ -1110,7 +1197,7 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
             zchunk = zlen = div_up(ze - zb, nchunks);
             zgroups = div_up(ze - zb, zchunk);
         }
-        dim3 b(64, 8, 1), g(div_up(s->nx, 64), div_up(s->ny, 8), zgroups);
+        dim3 b(64, TY, 1), g(div_up(s->nx, 64), div_up(s->ny, TY), zgroups);
         double* res_part = nullptr;
         if (with_res) {   // the launches of one advection write their partials one after the other
             const size_t blocks = (size_t)g.x * g.y * g.z;
@@ -2000,8 +2087,22 @@ int fs3d_gauss_seidel_projection(fs3d_sim* s, double* change) {
 int fs3d_sweeps(fs3d_sim* s, int n) {
     SIM_GUARD(s);
     FS_TRY(prepare(s));
-    for (int i = 0; i < n; ++i) FS_TRY(DISPATCH(s, sweep_once, s));
+    FS_TRY(DISPATCH(s, sweeps_n, s, n));
     halos_after_sweeps(s);
+    return FS_OK;
+}
+
+int fs3d_time_sweep_pairs(fs3d_sim* s, int npairs, double* ms) {
+    SIM_GUARD(s);
+    if (!pairs_possible(s)) return set_err(s, FS_ESTATE, "two sweeps per pass need a single domain, red-black order, FS_SWEEP_FUSED and an even nx");
+    FS_TRY(prepare(s));
+    SIM_HIP(hipEventRecord(s->ev[0], s->stream));
+    for (int i = 0; i < npairs; ++i) FS_TRY(DISPATCH(s, sweep_pair, s));
+    SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+    SIM_HIP(hipEventSynchronize(s->ev[1]));
+    float t = 0;
+    SIM_HIP(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+    if (ms) *ms = t;
     return FS_OK;
 }
 

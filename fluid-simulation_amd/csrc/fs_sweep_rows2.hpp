@@ -1,0 +1,286 @@
+// TWO full red-black sweeps in one pass over HBM: the register-resident one-pass sweep
+// (fs_sweep_rows.hpp) carried one level further.
+//
+// The one-pass sweep is bound by memory (its vector ALUs are about a third busy), and a projection that
+// needs K sweeps reads and writes the velocity K times.  Here a workgroup applies, per step t of its march
+// along z, the first colour of sweep 1 to plane t, the second colour of sweep 1 to plane t-1, the first
+// colour of sweep 2 to plane t-2 and the second colour of sweep 2 to plane t-3, and stores plane t-3: every
+// face is read once and written once per TWO sweeps (12.5 B per cell and sweep).
+//
+// Why the arithmetic is that of four separate half-sweeps: a cell visit (advection-reflection/
+// main.cpp:198-233) touches only the cell's own six faces, and a half-sweep of one colour needs the
+// previous half-sweep finished on the six neighbours of every cell it visits.  The neighbours in the
+// same plane and in the plane below were visited in earlier steps (there is a barrier between steps);
+// the neighbour above is the cell directly above in the same column, which the same lane has just
+// visited in the same step (w never leaves the lane).  The four phases of a step work on four different
+// planes, so they do not meet in LDS either.
+//
+// Each half-sweep lets one more ring of a tile go stale (its cells lack the visits of cells outside the
+// tile): tiles overlap by eight cells in x and y, z-chunks by four planes either side, and the stored
+// core is exact.  Output goes to the other generation of the arrays.  Single domain only: a z-slab holds
+// two halo planes, a pass of two sweeps would need four.
+#pragma once
+#include <type_traits>
+#include "fs_kernels3d.hpp"
+#include "fs_sweep_rows.hpp"
+
+namespace fsamd {
+
+template <typename T, int NSEG, int CP>
+struct Rows2Cfg {
+    static constexpr int RY = 16;           // rows (waves) of a workgroup
+    static constexpr int SEGW = 128 * CP;
+    static constexpr int W = SEGW * NSEG;
+    static constexpr int NQ = NSEG * CP;
+    static constexpr int NPV = 5;           // v planes in LDS: one per phase of a step and the plane being stored
+    static constexpr int S = 4;             // rings of a tile that go stale (one per half-sweep)
+    static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
+};
+
+template <typename T, int NSEG, int CP>
+__global__ void __launch_bounds__(1024, 4)
+k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
+           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
+           int zb, int ze, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
+    using C = Rows2Cfg<T, NSEG, CP>;
+    constexpr int NQ = C::NQ, S = C::S;
+    using VecT = Vec<T, 2 * CP>;
+    using FlagWord = typename std::conditional<CP == 1, uint16_t, uint32_t>::type;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][rows][W], a row de-interleaved as in k_rb_rows
+
+    const int lane = threadIdx.x, ry = threadIdx.y;
+    // workgroups sharing an XCD are y-neighbours of one z-chunk (see k_rb_rows)
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int xcd = lin & 7, qq = total >> 3, rem = total & 7;
+    const int logical = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (lin >> 3);
+    const int by = logical % nty, bx = (logical / nty) % ntx, bz = logical / (nty * ntx);
+    // A launch may cover only some of the tiles of a row (the rest being left to a launch of another tile width):
+    // xbase is the origin of its first tile, xedges says whether its first (bit 0) and last (bit 1) tiles touch
+    // the domain boundary.
+    const int xr0 = xbase + bx * (C::W - 2 * S), yr0 = by * (rows - 2 * S);
+    const int y = yr0 + ry;
+    const bool row_in = y < g.ny;
+    const int cx_lo = (bx == 0 && (xedges & 1)) ? 0 : xr0 + S, cx_hi = (bx == ntx - 1 && (xedges & 2)) ? g.nx : xr0 + C::W - S;
+    const int cy_lo = by == 0 ? 0 : yr0 + S, cy_hi = by == nty - 1 ? g.ny : yr0 + rows - S;
+    const bool row_core = y >= cy_lo && y < cy_hi;
+
+    // planes [c0, c1) are stored.  The last half-sweep visits [c0 - 1, c1) (the low-z face of plane c0 is the
+    // high-z face of the cells below it), every earlier one a plane more on either side, all inside the planes
+    // the sweep relaxes, [zb, ze)
+    const int c0 = bz * zchunk, c1 = min(c0 + zchunk, g.nzl);
+    const int r4b = max(zb, c0 - 1), r4e = min(ze, c1);
+    const int r3b = max(zb, c0 - 2), r3e = min(ze, c1 + 1);
+    const int r2b = max(zb, c0 - 3), r2e = min(ze, c1 + 2);
+    const int r1b = max(zb, c0 - 4), r1e = min(ze, c1 + 3);
+    const int lb = max(0, c0 - 4), le = min(g.nzl, c1 + 4);
+
+    // Rows (waves) a half-sweep has to visit.  The k-th half-sweep is wrong on row k-2 from a tile edge that is not
+    // a domain edge (it reads a face the half-sweep before left stale there) and nobody needs its rows further out;
+    // the last row of a tile never visits (the v of the row above it is not held).
+    const int lo2 = by == 0 ? 0 : 1, lo3 = by == 0 ? 0 : 2, lo4 = by == 0 ? 0 : 3;
+    const bool top = by == nty - 1;
+    const int hi1 = rows - 1, hi2 = top ? rows - 1 : rows - 2, hi3 = top ? rows - 1 : rows - 3, hi4 = top ? rows - 1 : rows - 4;
+
+    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * CP * lane;
+    bool seg_in[NSEG], pair_core[NQ];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int x = xr0 + sg * C::SEGW + 2 * CP * lane;
+        seg_in[sg] = row_in && x < g.nx;
+#pragma unroll
+        for (int j = 0; j < CP; ++j) pair_core[sg * CP + j] = row_core && x + 2 * j >= cx_lo && x + 2 * j < cx_hi;
+    }
+
+    RowPlane<T, NQ, NSEG> A, B, Cc, D, E, F;   // planes t-3, t-2, t-1, t, t+1 (u, flags; w since a step earlier), t+2 (w)
+    VecT vst[NSEG];
+
+    auto load_uf = [&](RowPlane<T, NQ, NSEG>& X, int p) {
+        const bool pin = p >= lb && p < le;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const bool in = pin && seg_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
+            VecT pu, pv;
+            uint32_t fw = CP == 1 ? 0x8080u : 0x80808080u;   // FL_SELF_OBJECT in every byte
+#pragma unroll
+            for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; }
+            if (in) {
+                pu = *reinterpret_cast<const VecT*>(ui + i);
+                pv = *reinterpret_cast<const VecT*>(vi + i);
+                fw = *reinterpret_cast<const FlagWord*>(flags + i);
+            }
+            X.f[sg] = fw;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { X.u[sg * CP + j][0] = pu.e[2 * j]; X.u[sg * CP + j][1] = pu.e[2 * j + 1]; }
+            vst[sg] = pv;
+        }
+    };
+    auto load_w = [&](RowPlane<T, NQ, NSEG>& X, int p) {
+        const bool pin = p >= lb && p < le;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const bool in = pin && seg_in[sg];
+            const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
+            VecT pw;
+#pragma unroll
+            for (int k = 0; k < 2 * CP; ++k) pw.e[k] = 0;
+            if (in) pw = *reinterpret_cast<const VecT*>(wi + i);
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { X.w[sg * CP + j][0] = pw.e[2 * j]; X.w[sg * CP + j][1] = pw.e[2 * j + 1]; }
+        }
+    };
+    auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 2 * C::NPV) % C::NPV) * rows + row) * C::W; };
+    auto vpos = [&](int q, int c) { return (2 * q + c) * 64 + lane; };
+    auto stage_v = [&](int p) {
+        T* row = vrow(p, ry);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+            for (int j = 0; j < CP; ++j) {
+                row[vpos(sg * CP + j, 0)] = vst[sg].e[2 * j];
+                row[vpos(sg * CP + j, 1)] = vst[sg].e[2 * j + 1];
+            }
+    };
+    // One colour on plane p (X = plane p, Y = plane p+1): the visit of k_rb_rows.
+    auto relax = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
+        const int c = (colour + xr0 + y + p + g.gz0) & 1;
+        T* v0row = vrow(p, ry);
+        T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
+        const bool row_ok = ry < rows - 1;
+        T send[NQ];
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t fl = (X.f[q / CP] >> (16 * (q % CP))) & 0xffu;
+                const bool ok = row_ok && relaxes(fl);
+                const int a = vpos(q, 0);
+                const T u0 = X.u[q][0], u1 = X.u[q][1];
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[q][0], w1 = Y.w[q][0];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
+                if (omega != (T)1) dd = omega * dd;
+                const bool self = fl & FL_SELF_FLUID;
+                if (ok && (fl & FL_XM) && self) X.u[q][0] = u0 + dd;
+                if (ok && (fl & FL_XP)) X.u[q][1] = u1 - dd;
+                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
+                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[q][0] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[q][0] = w1 - dd;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int sg = q / CP, j = q % CP;
+                const uint32_t fl = (X.f[sg] >> (16 * j + 8)) & 0xffu;
+                T u1;
+                bool have_hi = true;
+                if (j + 1 < CP) {
+                    u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
+                } else {
+                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);
+                    if (sg + 1 < NSEG) {
+                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], 0, 64);
+                        if (lane == 63) u1 = wrap;
+                    } else {
+                        have_hi = lane < 63;
+                    }
+                }
+                const bool ok = row_ok && have_hi && relaxes(fl);
+                const int a = vpos(q, 1);
+                const T u0 = X.u[q][1];
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[q][1], w1 = Y.w[q][1];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                T dd = div / (T)(ok ? __popc(fl & FL_NBR) : 1);
+                if (omega != (T)1) dd = omega * dd;
+                const bool self = fl & FL_SELF_FLUID;
+                if (ok && (fl & FL_XM) && self) X.u[q][1] = u0 + dd;
+                send[q] = (ok && (fl & FL_XP)) ? dd : (T)0;
+                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
+                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
+                if (ok && (fl & FL_ZM) && self) X.w[q][1] = w0 + dd;
+                if (ok && (fl & FL_ZP)) Y.w[q][1] = w1 - dd;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int sg = q / CP, j = q % CP;
+                T got;
+                bool any = true;
+                if (j > 0) {
+                    got = send[q > 0 ? q - 1 : 0];
+                } else {
+                    got = __shfl_up(send[sg * CP + CP - 1], 1, 64);
+                    any = lane > 0;
+                    if (sg > 0) {
+                        const T wrap = __shfl(send[(sg > 0 ? sg : 1) * CP - 1], 63, 64);
+                        if (lane == 0) { got = wrap; any = true; }
+                    }
+                }
+                if (any && got != (T)0) X.u[q][0] = X.u[q][0] - got;
+            }
+        }
+    };
+    auto store_plane = [&](RowPlane<T, NQ, NSEG>& X, int p) {
+        const T* row = vrow(p, ry);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const int64_t i = (int64_t)p * g.sz + rowoff + sg * C::SEGW;
+            bool all = true, none = true;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) { all = all && pair_core[sg * CP + j]; none = none && !pair_core[sg * CP + j]; }
+            if (none) continue;
+            VecT pu, pv, pw;
+#pragma unroll
+            for (int j = 0; j < CP; ++j) {
+                const int q = sg * CP + j;
+                pu.e[2 * j] = X.u[q][0]; pu.e[2 * j + 1] = X.u[q][1];
+                pv.e[2 * j] = row[vpos(q, 0)]; pv.e[2 * j + 1] = row[vpos(q, 1)];
+                pw.e[2 * j] = X.w[q][0]; pw.e[2 * j + 1] = X.w[q][1];
+            }
+            if (all) {
+                *reinterpret_cast<VecT*>(uo + i) = pu;
+                *reinterpret_cast<VecT*>(vo + i) = pv;
+                *reinterpret_cast<VecT*>(wo + i) = pw;
+            } else {
+#pragma unroll
+                for (int j = 0; j < CP; ++j)
+                    if (pair_core[sg * CP + j]) {
+                        using Pr = Vec<T, 2>;
+                        *reinterpret_cast<Pr*>(uo + i + 2 * j) = Pr{{pu.e[2 * j], pu.e[2 * j + 1]}};
+                        *reinterpret_cast<Pr*>(vo + i + 2 * j) = Pr{{pv.e[2 * j], pv.e[2 * j + 1]}};
+                        *reinterpret_cast<Pr*>(wo + i + 2 * j) = Pr{{pw.e[2 * j], pw.e[2 * j + 1]}};
+                    }
+            }
+        }
+    };
+
+    // Step t: Z = plane t-4, A = t-3, B = t-2, Cc = t-1, D = t, E = t+1, F = t+2.  u, flags and v of a plane are
+    // fetched one step before its first visit, w two steps before (it is the high-z face of the plane below).  The
+    // planes move down one name per step (register moves: the vector ALUs have the time); what a step fetches is
+    // moved at the start of the NEXT step, so that a fetch has a whole step to arrive.  A plane is stored one step
+    // after its last visit: the barrier that opens a step is then the only one (it also separates that visit, which
+    // other waves made to this wave's v row, from the store).
+    RowPlane<T, NQ, NSEG> Z;
+    load_uf(Z, -1); load_uf(A, -1); load_uf(B, -1); load_uf(Cc, -1); load_uf(D, -1); load_uf(E, -1); load_uf(F, -1);
+    load_w(Z, -1); load_w(A, -1); load_w(B, -1); load_w(Cc, -1); load_w(D, -1); load_w(E, -1);
+    load_w(F, lb);   // the step before the first one "fetched" the w of plane lb
+    for (int t = lb - 1; t <= c1 + 3; ++t) {
+        if (t >= lb && t < le) stage_v(t);            // the v fetched with plane t in the step before
+        D = E;                                         // plane t: u and flags fetched in the step before, w the step before that
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { E.w[q][0] = F.w[q][0]; E.w[q][1] = F.w[q][1]; }
+        load_uf(E, t + 1);
+        load_w(F, t + 2);
+        __syncthreads();
+        if (t - 4 >= c0 && t - 4 < c1) store_plane(Z, t - 4);
+        if (t >= r1b && t < r1e && ry < hi1) relax(D, E, t, 0);
+        if (t - 1 >= r2b && t - 1 < r2e && ry >= lo2 && ry < hi2) relax(Cc, D, t - 1, 1);
+        if (t - 2 >= r3b && t - 2 < r3e && ry >= lo3 && ry < hi3) relax(B, Cc, t - 2, 0);
+        if (t - 3 >= r4b && t - 3 < r4e && ry >= lo4 && ry < hi4) relax(A, B, t - 3, 1);
+        Z = A; A = B; B = Cc; Cc = D;
+    }
+}
+
+}  // namespace fsamd

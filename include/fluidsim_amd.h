@@ -89,7 +89,9 @@ enum {
 /* implementation of one red-black sweep (same result bit for bit) */
 enum {
     FS_SWEEP_FUSED = 0,      /* both colours in one pass over HBM, out of place: the register-resident
-                                kernel when nx is even, else the LDS-window kernel                 */
+                                kernel when nx is even, else the LDS-window kernel; on a single
+                                domain with an even nx, two consecutive sweeps that no evaluation
+                                of the stopping rule separates run as ONE pass over HBM            */
     FS_SWEEP_TWO_PASS = 1,   /* one in-place launch per colour                                     */
     FS_SWEEP_FUSED_LDS = 2   /* both colours in one pass, always the LDS-window kernel             */
 };
@@ -229,6 +231,10 @@ int fs3d_sweeps(fs3d_sim *sim, int n);
  * two events on that stream; *ms receives the device time between them (the
  * reference times whole frames with std::chrono, main.cpp:502, :541-543).    */
 int fs3d_time_sweeps(fs3d_sim *sim, int n, double *ms);
+/* The same for passes of two sweeps each (what fs3d_project and fs3d_sweeps use between evaluations of the
+ * stopping rule on a single domain with FS_SWEEP_FUSED and an even nx: one launch applies two full red-black
+ * sweeps in one pass over HBM, bit for bit two launches of one sweep); FS_ESTATE where that kernel does not apply. */
+int fs3d_time_sweep_pairs(fs3d_sim *sim, int npairs, double *ms);
 /* The same for the advection: n advections of length t_step back to back (reflected == 0: semi_lagrange of
  * the current state, main.cpp:256-291; else the second half advection of the advection-reflection step,
  * which carries the reflection of a copy of the current velocity), *ms = device time between the events.   */

@@ -1,0 +1,14 @@
+"""One-pass sweep against the pass of two sweeps: milliseconds per sweep."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fsamd_loader
+fs = fsamd_loader.load()
+for n in [int(a) for a in sys.argv[1:]] or [128, 256, 512]:
+    g = fs.FluidSim3D(n, n, n, stop_mode=fs.STOP_FIXED, max_iters=1)
+    g.sphere_influence(n / 10.0)
+    g.time_sweeps(4); one = g.time_sweeps(20) / 20
+    g.time_sweep_pairs(2); two = g.time_sweep_pairs(10) / 20
+    cells = n ** 3
+    print(f"{n}^3: one sweep per pass {one * 1e3:.1f} us per sweep ({25 * cells / one / 1e6:.0f} GB/s); two per pass "
+          f"{two * 1e3:.1f} us per sweep ({12.5 * cells / two / 1e6:.0f} GB/s of HBM model traffic, {50 * cells / two / 1e6:.0f} GB/s algorithmic)", flush=True)
+    g.close()

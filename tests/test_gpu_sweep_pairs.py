@@ -1,0 +1,58 @@
+"""Two sweeps in one pass over HBM (k_rb_rows2) against the oracle's separate sweeps, bit for bit: shapes with one and
+several tiles in x and y, several z-chunks, rows that are and are not multiples of 16 bytes, both precisions, masks
+with Object and StaticFluid cells, over-relaxation; and the projection loop, which must stop on the same sweep and
+leave the same field whether or not its sweeps run in pairs."""
+import numpy as np
+import pytest
+
+from tests.util3d import assert_fields_equal, make_pair
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(20, 13, 11), (8, 3, 3), (4, 40, 5), (260, 40, 24), (64, 70, 50), (132, 18, 9), (30, 21, 17), (516, 20, 12),
+          (96, 33, 140), (258, 19, 7)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sweep_pairs_bit_exact(fsamd, shape, dtype):
+    nx, ny, nz = shape
+    o, g = make_pair(fsamd, nx, ny, nz, seed=nx + ny + nz, dtype=dtype, stop_mode=fsamd.STOP_FIXED, max_iters=1)
+    done = 0
+    for n in (2, 3, 4):          # a pair; a pair and a single sweep; two pairs
+        g.sweeps(n)
+        done += n
+        o.project_rb(stop_mode=0, max_iter=n)
+        assert_fields_equal(o, g, "uvw", what=f"{shape} {dtype.__name__} after {done} sweeps")
+
+
+def test_sweep_pairs_with_over_relaxation(fsamd):
+    o, g = make_pair(fsamd, 72, 37, 29, seed=5, omega=1.3, stop_mode=fsamd.STOP_FIXED, max_iters=6)
+    g.project()
+    o.project_rb(omega=1.3, stop_mode=0, max_iter=6)
+    assert_fields_equal(o, g, "uvw", what="omega 1.3")
+
+
+@pytest.mark.parametrize("stop_mode,tol,check_every", [(2, 2e-5, 1), (2, 2e-5, 3), (2, 2e-5, 0), (1, 2.0, 2), (1, 2.0, 1)])
+def test_projection_stops_on_the_same_sweep_with_and_without_pairs(fsamd, stop_mode, tol, check_every):
+    # FS_SWEEP_FUSED pairs its sweeps between evaluations; FS_SWEEP_FUSED_LDS never does
+    cfg = dict(seed=11, scale=5.0, stop_mode=stop_mode, tol=tol, max_iters=60, check_every=check_every)
+    _, a = make_pair(fsamd, 48, 30, 26, sweep_kernel=fsamd.SWEEP_FUSED, **cfg)
+    _, b = make_pair(fsamd, 48, 30, 26, sweep_kernel=fsamd.SWEEP_FUSED_LDS, **cfg)
+    for _ in range(2):
+        na, ma = a.project()
+        nb, mb = b.project()
+        assert na == nb and 1 < na <= 60, (na, ma)
+        assert ma == pytest.approx(mb, rel=1e-12)
+        for k in range(3):
+            assert np.array_equal(a.get_field(k), b.get_field(k))
+        a.semi_lagrange(0.02); b.semi_lagrange(0.02)
+
+
+def test_reflection_steps_with_paired_sweeps_equal_the_oracle(fsamd):
+    from tests.test_gpu_north_star import reflection_step_oracle
+    o, g = make_pair(fsamd, 40, 36, 34, seed=2, scale=3.0, step_mode=fsamd.STEP_REFLECTION, stop_mode=fsamd.STOP_FIXED, max_iters=5)
+    for step in range(2):
+        g.advance(0.02)
+        reflection_step_oracle(o, np.float32(0.02), 5)
+        assert_fields_equal(o, g, what=f"reflection step {step} with 5 sweeps per projection")

@@ -664,13 +664,14 @@ int launch_rows2_tiles(fs3d_sim* s, int ntx, int xbase, int xedges, int cv, int 
     Part& p = s->parts[0];
     const int rows = std::min(C::RY, s->ny);
     const int nty = s->ny <= rows ? 1 : div_up(s->ny - 2 * C::S, rows - 2 * C::S);
-    // z-chunks: rounds of workgroups over the CUs (one workgroup of 16 waves per CU) x planes a workgroup marches
-    // through (its chunk, the eight planes of overlap and the pipeline)
+    // z-chunks: rounds of workgroups over the CUs x planes a workgroup marches through (its chunk, the eight planes
+    // of overlap and the pipeline).  The narrow variant needs few registers: two of its workgroups share a CU.
+    const int per_cu = NSEG * CP * sizeof(T) <= 4 ? 2 : 1;
     int best_c = 1;
     double best = 1e300;
     for (int c = 1; c <= std::max(1, p.g.nzl / 8); ++c) {
         const int zc = div_up(p.g.nzl, c);
-        const double cost = (double)div_up(ntx * nty * div_up(p.g.nzl, zc), s->num_cus) * (zc + 12);
+        const double cost = (double)div_up(ntx * nty * div_up(p.g.nzl, zc), per_cu * s->num_cus) * (zc + 12);
         if (cost < best) { best = cost; best_c = c; }
     }
     const int zchunk = div_up(p.g.nzl, best_c), zgroups = div_up(p.g.nzl, zchunk);

@@ -7,6 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 g = fs.FluidSim3D(n, n, n, stop_mode=0, max_iters=1)
 g.sphere_influence(n / 10.0)
 print("ms per sweep", g.time_sweeps(6) / 6)
+print("ms per pass of two sweeps", g.time_sweep_pairs(6) / 6)
 # kernels with exactly known traffic, to calibrate the counters on this access pattern:
 # k_change_l1 reads 24 B per interior cell, k_div_sumsq reads 13 B per interior cell, both write ~nothing
 for _ in range(3):

@@ -655,48 +655,67 @@ bool pairs_possible(const fs3d_sim* s) {
            s->nparts_global == 1;
 }
 
-// One launch of the two-sweep kernel over `ntx` tiles of a row starting at column xbase.
-template <typename T, int NSEG, int CP>
-int launch_rows2_tiles(fs3d_sim* s, int ntx, int xbase, int xedges, int cv, int ov) {
-    using C = Rows2Cfg<T, NSEG, CP>;
-    auto kern = k_rb_rows2<T, NSEG, CP>;
+// The launch of the two-sweep kernel for one choice of lanes per row: tiles of W columns x `rows` rows overlapping by 8,
+// z-chunks, and the number of steps the slowest CU marches (rounds of workgroups x planes of a workgroup: its chunk,
+// the eight planes of overlap and the pipeline).
+struct Rows2Plan { int waves, rows, ntx, nty, zchunk, zgroups; double steps; };
+
+template <typename C>
+Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu) {
+    Rows2Plan t;
+    // an even number of waves: the rows of a wave then have one colour
+    t.waves = std::min(C::WAVES, 2 * div_up(div_up(s->ny, C::RPW), 2));
+    t.rows = t.waves * C::RPW;
+    t.nty = s->ny <= t.rows ? 1 : div_up(s->ny - 2 * C::S, t.rows - 2 * C::S);
+    t.ntx = s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
+    const int nzl = s->parts[0].g.nzl;
+    int best_c = 1;
+    t.steps = 1e300;
+    for (int c = 1; c <= std::max(1, nzl / 8); ++c) {
+        const int zc = div_up(nzl, c);
+        const double cost = (double)div_up(t.ntx * t.nty * div_up(nzl, zc), per_cu * s->num_cus) * (zc + 12);
+        if (cost < t.steps) { t.steps = cost; best_c = c; }
+    }
+    t.zchunk = div_up(nzl, best_c);
+    t.zgroups = div_up(nzl, t.zchunk);
+    return t;
+}
+
+template <typename T, int NSEG, int CP, int LPR>
+int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov) {
+    using C = Rows2Cfg<T, NSEG, CP, LPR>;
+    auto kern = k_rb_rows2<T, NSEG, CP, LPR>;
     SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
     Part& p = s->parts[0];
-    const int rows = std::min(C::RY, s->ny);
-    const int nty = s->ny <= rows ? 1 : div_up(s->ny - 2 * C::S, rows - 2 * C::S);
-    // z-chunks: rounds of workgroups over the CUs x planes a workgroup marches through (its chunk, the eight planes
-    // of overlap and the pipeline).  The narrow variant needs few registers: two of its workgroups share a CU.
-    const int per_cu = NSEG * CP * sizeof(T) <= 4 ? 2 : 1;
-    int best_c = 1;
-    double best = 1e300;
-    for (int c = 1; c <= std::max(1, p.g.nzl / 8); ++c) {
-        const int zc = div_up(p.g.nzl, c);
-        const double cost = (double)div_up(ntx * nty * div_up(p.g.nzl, zc), per_cu * s->num_cus) * (zc + 12);
-        if (cost < best) { best = cost; best_c = c; }
-    }
-    const int zchunk = div_up(p.g.nzl, best_c), zgroups = div_up(p.g.nzl, zchunk);
-    dim3 b(64, rows, 1), g(ntx * nty * zgroups, 1, 1);
+    dim3 b(64, t.waves, 1), g(t.ntx * t.nty * t.zgroups, 1, 1);
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
-                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, zchunk, ntx, nty, rows, xbase, xedges);
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, 0, 3);
     return FS_OK;
 }
 
-// Tiles of W columns overlap by 8, so a row of nx columns takes ceil((nx - 8) / (W - 8)) of them; where the last of
-// these would hold few columns (nx = 512 is two tiles of 256 and sixteen columns) it goes to a launch of the narrow
-// variant instead, which marches through half the lanes.
+// The tile shape is chosen per grid.  A workgroup is 16 waves whatever its shape (256 x 16, 128 x 32 or 64 x 64 cells at
+// 4-byte elements), and squarer tiles lose a smaller share of their cells to the stale rings; the estimate is the
+// number of steps of the plan times the measured cost of a step of that shape relative to 128 x 32: 0.8 for one row
+// per wave (waves whose row is stale in a half-sweep skip it), 0.95 to 1.55 for four rows per wave (a wave then
+// loads from four rows sixteen rows apart, which costs more the longer the rows are: 4.2 us per step at 256 columns,
+// 6.8 at 512 against 4.4 for two rows).  FSAMD_ROWS2_LANES_PER_ROW = 64 | 32 | 16 fixes the shape (tests, measurements).
 template <typename T, int NSEG, int CP>
 int launch_rows2(fs3d_sim* s) {
-    using C = Rows2Cfg<T, NSEG, CP>;
     if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
     const int cv = s->curv, ov = s->curv ^ 1;
-    const int ntx = s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
-    const int last_origin = (ntx - 1) * (C::W - 2 * C::S), last_cols = s->nx - last_origin;
-    if (ntx >= 2 && C::W > 128 && last_cols <= 128) {
-        FS_TRY((launch_rows2_tiles<T, NSEG, CP>(s, ntx - 1, 0, 1, cv, ov)));
-        FS_TRY((launch_rows2_tiles<T, 1, 1>(s, 1, last_origin, 2, cv, ov)));
-    } else {
-        FS_TRY((launch_rows2_tiles<T, NSEG, CP>(s, ntx, 0, 3, cv, ov)));
+    const int per_cu = NSEG * CP * sizeof(T) <= 4 ? 2 : 1;   // the narrow variant needs few registers: two workgroups share a CU
+    const Rows2Plan t64 = rows2_plan<Rows2Cfg<T, NSEG, CP, 64>>(s, per_cu), t32 = rows2_plan<Rows2Cfg<T, NSEG, CP, 32>>(s, per_cu),
+                    t16 = rows2_plan<Rows2Cfg<T, NSEG, CP, 16>>(s, per_cu);
+    const char* want = getenv("FSAMD_ROWS2_LANES_PER_ROW");   // read per call: tests switch it between simulations
+    int lpr = want ? atoi(want) : 0;
+    if (lpr != 64 && lpr != 32 && lpr != 16) {
+        const size_t row_bytes = (size_t)s->nx * sizeof(T);
+        const double c64 = 0.8 * t64.steps, c32 = t32.steps, c16 = (row_bytes <= 1024 ? 0.95 : row_bytes < 2048 ? 1.15 : 1.55) * t16.steps;
+        lpr = c64 <= c32 && c64 <= c16 ? 64 : c32 <= c16 ? 32 : 16;
     }
+    if (lpr == 64) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, t64, cv, ov)));
+    else if (lpr == 32) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, t32, cv, ov)));
+    else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, t16, cv, ov)));
     SIM_HIP(hipGetLastError());
     s->curv ^= 1;
     return FS_OK;

@@ -26,30 +26,40 @@
 
 namespace fsamd {
 
-template <typename T, int NSEG, int CP>
+// LPR lanes of a wave share a row, so a wave holds 64 / LPR rows and a workgroup of 16 waves a tile of
+// (LPR * 2 * CP * NSEG) columns x (16 * 64 / LPR) rows: the same number of cells whatever LPR is, but a squarer
+// tile loses a smaller share of them to the stale rings.  The rows of a wave lie two apart, so they have one colour
+// and the wave takes one branch of a visit (the number of waves is even).
+template <typename T, int NSEG, int CP, int LPR = 64>
 struct Rows2Cfg {
-    static constexpr int RY = 16;           // rows (waves) of a workgroup
-    static constexpr int SEGW = 128 * CP;
+    static constexpr int WAVES = 16;        // waves of a workgroup
+    static constexpr int RPW = 64 / LPR;    // rows of a wave
+    static constexpr int RY = WAVES * RPW;  // rows of a tile
+    static constexpr int SEGW = 2 * LPR * CP;
     static constexpr int W = SEGW * NSEG;
     static constexpr int NQ = NSEG * CP;
     static constexpr int NPV = 5;           // v planes in LDS: one per phase of a step and the plane being stored
     static constexpr int S = 4;             // rings of a tile that go stale (one per half-sweep)
-    static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
+    static constexpr size_t lds_bytes() { return (size_t)NPV * WAVES * 2 * NQ * 64 * sizeof(T); }
 };
 
-template <typename T, int NSEG, int CP>
+template <typename T, int NSEG, int CP, int LPR>
 __global__ void __launch_bounds__(1024, 4)
 k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
            T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
            int zb, int ze, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
-    using C = Rows2Cfg<T, NSEG, CP>;
+    using C = Rows2Cfg<T, NSEG, CP, LPR>;
     constexpr int NQ = C::NQ, S = C::S;
     using VecT = Vec<T, 2 * CP>;
     using FlagWord = typename std::conditional<CP == 1, uint16_t, uint32_t>::type;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][rows][W], a row de-interleaved as in k_rb_rows
+    T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][waves][2 * NQ][64]: a wave's lanes side by side, whatever rows they hold
 
-    const int lane = threadIdx.x, ry = threadIdx.y;
+    const int lane = threadIdx.x, ry = threadIdx.y, waves = blockDim.y;
+    const int lx = lane & (LPR - 1), sub = lane / LPR;
+    // row of the tile this lane works on: a pair of waves shares 2 * RPW adjacent rows, the even wave takes the
+    // even ones
+    const int r = (ry >> 1) * (2 * C::RPW) + 2 * sub + (ry & 1);
     // workgroups sharing an XCD are y-neighbours of one z-chunk (see k_rb_rows)
     const int total = gridDim.x, lin = blockIdx.x;
     const int xcd = lin & 7, qq = total >> 3, rem = total & 7;
@@ -59,7 +69,7 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     // xbase is the origin of its first tile, xedges says whether its first (bit 0) and last (bit 1) tiles touch
     // the domain boundary.
     const int xr0 = xbase + bx * (C::W - 2 * S), yr0 = by * (rows - 2 * S);
-    const int y = yr0 + ry;
+    const int y = yr0 + r;
     const bool row_in = y < g.ny;
     const int cx_lo = (bx == 0 && (xedges & 1)) ? 0 : xr0 + S, cx_hi = (bx == ntx - 1 && (xedges & 2)) ? g.nx : xr0 + C::W - S;
     const int cy_lo = by == 0 ? 0 : yr0 + S, cy_hi = by == nty - 1 ? g.ny : yr0 + rows - S;
@@ -82,11 +92,11 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     const bool top = by == nty - 1;
     const int hi1 = rows - 1, hi2 = top ? rows - 1 : rows - 2, hi3 = top ? rows - 1 : rows - 3, hi4 = top ? rows - 1 : rows - 4;
 
-    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * CP * lane;
+    const int64_t rowoff = (int64_t)y * g.sy + xr0 + 2 * CP * lx;
     bool seg_in[NSEG], pair_core[NQ];
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
-        const int x = xr0 + sg * C::SEGW + 2 * CP * lane;
+        const int x = xr0 + sg * C::SEGW + 2 * CP * lx;
         seg_in[sg] = row_in && x < g.nx;
 #pragma unroll
         for (int j = 0; j < CP; ++j) pair_core[sg * CP + j] = row_core && x + 2 * j >= cx_lo && x + 2 * j < cx_hi;
@@ -130,7 +140,7 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
             for (int j = 0; j < CP; ++j) { X.w[sg * CP + j][0] = pw.e[2 * j]; X.w[sg * CP + j][1] = pw.e[2 * j + 1]; }
         }
     };
-    auto vrow = [&](int p, int row) { return sv + ((size_t)((p + 2 * C::NPV) % C::NPV) * rows + row) * C::W; };
+    auto vrow = [&](int p, int wv) { return sv + ((size_t)((p + 2 * C::NPV) % C::NPV) * waves + wv) * (2 * NQ * 64); };
     auto vpos = [&](int q, int c) { return (2 * q + c) * 64 + lane; };
     auto stage_v = [&](int p) {
         T* row = vrow(p, ry);
@@ -146,8 +156,13 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     auto relax = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
         const int c = (colour + xr0 + y + p + g.gz0) & 1;
         T* v0row = vrow(p, ry);
-        T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
-        const bool row_ok = ry < rows - 1;
+        // the row above: the same lanes of the next wave (from an even wave); from an odd wave the next row of the
+        // wave before, LPR lanes further on, or, from its last row, the first row of the wave after
+        const bool row_ok = r < rows - 1;
+        T* v1row = !row_ok ? v0row
+                   : (ry & 1) == 0 ? vrow(p, ry + 1)
+                   : sub < C::RPW - 1 ? vrow(p, ry - 1) + LPR
+                                      : vrow(p, ry + 1) - (C::RPW - 1) * LPR;
         T send[NQ];
         if (c == 0) {
 #pragma unroll
@@ -181,10 +196,10 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                 } else {
                     u1 = __shfl_down(X.u[sg * CP][0], 1, 64);
                     if (sg + 1 < NSEG) {
-                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], 0, 64);
-                        if (lane == 63) u1 = wrap;
+                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], lane & ~(LPR - 1), 64);
+                        if (lx == LPR - 1) u1 = wrap;
                     } else {
-                        have_hi = lane < 63;
+                        have_hi = lx < LPR - 1;
                     }
                 }
                 const bool ok = row_ok && have_hi && relaxes(fl);
@@ -212,10 +227,10 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                     got = send[q > 0 ? q - 1 : 0];
                 } else {
                     got = __shfl_up(send[sg * CP + CP - 1], 1, 64);
-                    any = lane > 0;
+                    any = lx > 0;
                     if (sg > 0) {
-                        const T wrap = __shfl(send[(sg > 0 ? sg : 1) * CP - 1], 63, 64);
-                        if (lane == 0) { got = wrap; any = true; }
+                        const T wrap = __shfl(send[(sg > 0 ? sg : 1) * CP - 1], lane | (LPR - 1), 64);
+                        if (lx == 0) { got = wrap; any = true; }
                     }
                 }
                 if (any && got != (T)0) X.u[q][0] = X.u[q][0] - got;
@@ -275,10 +290,11 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
         load_w(F, t + 2);
         __syncthreads();
         if (t - 4 >= c0 && t - 4 < c1) store_plane(Z, t - 4);
-        if (t >= r1b && t < r1e && ry < hi1) relax(D, E, t, 0);
-        if (t - 1 >= r2b && t - 1 < r2e && ry >= lo2 && ry < hi2) relax(Cc, D, t - 1, 1);
-        if (t - 2 >= r3b && t - 2 < r3e && ry >= lo3 && ry < hi3) relax(B, Cc, t - 2, 0);
-        if (t - 3 >= r4b && t - 3 < r4e && ry >= lo4 && ry < hi4) relax(A, B, t - 3, 1);
+        // (the row conditions are per lane; the lanes of one row, which shuffle with each other, agree on them)
+        if (t >= r1b && t < r1e && r < hi1) relax(D, E, t, 0);
+        if (t - 1 >= r2b && t - 1 < r2e && r >= lo2 && r < hi2) relax(Cc, D, t - 1, 1);
+        if (t - 2 >= r3b && t - 2 < r3e && r >= lo3 && r < hi3) relax(B, Cc, t - 2, 0);
+        if (t - 3 >= r4b && t - 3 < r4e && r >= lo4 && r < hi4) relax(A, B, t - 3, 1);
         Z = A; A = B; B = Cc; Cc = D;
     }
 }

@@ -1,6 +1,7 @@
 """Two sweeps in one pass over HBM (k_rb_rows2) against the oracle's separate sweeps, bit for bit: shapes with one and
 several tiles in x and y, several z-chunks, rows that are and are not multiples of 16 bytes, both precisions, masks
-with Object and StaticFluid cells, over-relaxation; and the projection loop, which must stop on the same sweep and
+with Object and StaticFluid cells, over-relaxation, every tile shape of the kernel (one, two or four rows per wave)
+and the shape the library picks itself; and the projection loop, which must stop on the same sweep and
 leave the same field whether or not its sweeps run in pairs."""
 import numpy as np
 import pytest
@@ -10,20 +11,25 @@ from tests.util3d import assert_fields_equal, make_pair
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(20, 13, 11), (8, 3, 3), (4, 40, 5), (260, 40, 24), (64, 70, 50), (132, 18, 9), (30, 21, 17), (516, 20, 12),
-          (96, 33, 140), (258, 19, 7)]
+          (96, 33, 140), (258, 19, 7), (72, 150, 10)]
 
 
+@pytest.mark.parametrize("lanes_per_row", [0, 64, 32, 16])
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_sweep_pairs_bit_exact(fsamd, shape, dtype):
+def test_sweep_pairs_bit_exact(fsamd, monkeypatch, shape, dtype, lanes_per_row):
     nx, ny, nz = shape
+    if lanes_per_row:
+        monkeypatch.setenv("FSAMD_ROWS2_LANES_PER_ROW", str(lanes_per_row))
+    else:
+        monkeypatch.delenv("FSAMD_ROWS2_LANES_PER_ROW", raising=False)
     o, g = make_pair(fsamd, nx, ny, nz, seed=nx + ny + nz, dtype=dtype, stop_mode=fsamd.STOP_FIXED, max_iters=1)
     done = 0
     for n in (2, 3, 4):          # a pair; a pair and a single sweep; two pairs
         g.sweeps(n)
         done += n
         o.project_rb(stop_mode=0, max_iter=n)
-        assert_fields_equal(o, g, "uvw", what=f"{shape} {dtype.__name__} after {done} sweeps")
+        assert_fields_equal(o, g, "uvw", what=f"{shape} {dtype.__name__} lanes/row {lanes_per_row} after {done} sweeps")
 
 
 def test_sweep_pairs_with_over_relaxation(fsamd):

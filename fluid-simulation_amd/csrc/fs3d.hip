@@ -21,6 +21,7 @@
 #include <chrono>
 #include <mutex>
 #include <set>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -661,13 +662,13 @@ bool pairs_possible(const fs3d_sim* s) {
 struct Rows2Plan { int waves, rows, ntx, nty, zchunk, zgroups; double steps; };
 
 template <typename C>
-Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu) {
+Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu, int ntx = 0) {   // ntx: that many tiles of a row instead of all of it
     Rows2Plan t;
     // an even number of waves: the rows of a wave then have one colour
     t.waves = std::min(C::WAVES, 2 * div_up(div_up(s->ny, C::RPW), 2));
     t.rows = t.waves * C::RPW;
     t.nty = s->ny <= t.rows ? 1 : div_up(s->ny - 2 * C::S, t.rows - 2 * C::S);
-    t.ntx = s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
+    t.ntx = ntx > 0 ? ntx : s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
     const int nzl = s->parts[0].g.nzl;
     int best_c = 1;
     t.steps = 1e300;
@@ -682,39 +683,58 @@ Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu) {
 }
 
 template <typename T, int NSEG, int CP, int LPR>
-int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov) {
+int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov, int xbase = 0, int xedges = 3) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
     auto kern = k_rb_rows2<T, NSEG, CP, LPR>;
     SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
     Part& p = s->parts[0];
     dim3 b(64, t.waves, 1), g(t.ntx * t.nty * t.zgroups, 1, 1);
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
-                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, 0, 3);
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, xbase, xedges);
     return FS_OK;
 }
 
 // The tile shape is chosen per grid.  A workgroup is 16 waves whatever its shape (256 x 16, 128 x 32 or 64 x 64 cells at
 // 4-byte elements), and squarer tiles lose a smaller share of their cells to the stale rings; the estimate is the
-// number of steps of the plan times the measured cost of a step of that shape relative to 128 x 32: 0.8 for one row
-// per wave (waves whose row is stale in a half-sweep skip it), 0.95 to 1.55 for four rows per wave (a wave then
-// loads from four rows sixteen rows apart, which costs more the longer the rows are: 4.2 us per step at 256 columns,
-// 6.8 at 512 against 4.4 for two rows).  FSAMD_ROWS2_LANES_PER_ROW = 64 | 32 | 16 fixes the shape (tests, measurements).
+// number of steps of the plan times the measured cost of a step of that shape: 2.85 us with one row per wave at any
+// size (waves whose row is stale in a half-sweep skip it, and a wave reads a kilobyte of a row at a time), 3.2 to 4.7 us
+// with two rows per wave and 3.7 to 7.7 us with four, growing with the length of a row between 1 and 2 KiB (the
+// shorter pieces of longer rows are served worse by the memory system).
+// Where the last 256-column tile of a row would hold at most 64 (128) columns - nx = 512 is two tiles and sixteen
+// columns - those can go to a second launch of 64 x 64 (128 x 32) tiles instead: "64+16", "64+32".
+// FSAMD_ROWS2_LANES_PER_ROW = 64 | 32 | 16 | 64+16 | 64+32 fixes the shape (tests, measurements).
 template <typename T, int NSEG, int CP>
 int launch_rows2(fs3d_sim* s) {
     if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
     const int cv = s->curv, ov = s->curv ^ 1;
-    const int per_cu = NSEG * CP * sizeof(T) <= 4 ? 2 : 1;   // the narrow variant needs few registers: two workgroups share a CU
-    const Rows2Plan t64 = rows2_plan<Rows2Cfg<T, NSEG, CP, 64>>(s, per_cu), t32 = rows2_plan<Rows2Cfg<T, NSEG, CP, 32>>(s, per_cu),
-                    t16 = rows2_plan<Rows2Cfg<T, NSEG, CP, 16>>(s, per_cu);
-    const char* want = getenv("FSAMD_ROWS2_LANES_PER_ROW");   // read per call: tests switch it between simulations
-    int lpr = want ? atoi(want) : 0;
-    if (lpr != 64 && lpr != 32 && lpr != 16) {
-        const size_t row_bytes = (size_t)s->nx * sizeof(T);
-        const double c64 = 0.8 * t64.steps, c32 = t32.steps, c16 = (row_bytes <= 1024 ? 0.95 : row_bytes < 2048 ? 1.15 : 1.55) * t16.steps;
-        lpr = c64 <= c32 && c64 <= c16 ? 64 : c32 <= c16 ? 32 : 16;
+    using C64 = Rows2Cfg<T, NSEG, CP, 64>;
+    using C32 = Rows2Cfg<T, NSEG, CP, 32>;
+    using C16 = Rows2Cfg<T, NSEG, CP, 16>;
+    const int per_cu = 1;
+    const Rows2Plan t64 = rows2_plan<C64>(s, per_cu), t32 = rows2_plan<C32>(s, per_cu), t16 = rows2_plan<C16>(s, per_cu);
+    const int last_origin = (t64.ntx - 1) * (C64::W - 2 * C64::S), last_cols = s->nx - last_origin;
+    const int rest = t64.ntx < 2 ? 0 : last_cols <= C16::W ? 16 : last_cols <= C32::W ? 32 : 0;   // shape for the last columns
+    const Rows2Plan main64 = rest ? rows2_plan<C64>(s, per_cu, t64.ntx - 1) : t64;
+    const Rows2Plan rest_plan = rest == 16 ? rows2_plan<C16>(s, per_cu, 1) : rest == 32 ? rows2_plan<C32>(s, per_cu, 1) : t64;
+    enum { ONE64 = 64, ONE32 = 32, ONE16 = 16, SPLIT = 1 };
+    int shape = 0;
+    if (const char* want = getenv("FSAMD_ROWS2_LANES_PER_ROW")) {   // read per call: tests switch it between simulations
+        const std::string w(want);
+        shape = w == "64" ? ONE64 : w == "32" ? ONE32 : w == "16" ? ONE16 : (w == "64+16" && rest == 16) || (w == "64+32" && rest == 32) ? SPLIT : 0;
     }
-    if (lpr == 64) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, t64, cv, ov)));
-    else if (lpr == 32) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, t32, cv, ov)));
+    if (!shape) {
+        const double over = std::min(1.0, std::max(0.0, ((double)s->nx * sizeof(T) - 1024.0) / 1024.0));
+        const double k32 = 3.2 + 1.5 * over, k16 = 3.7 + 4.0 * over;
+        const double c64 = 2.85 * t64.steps, c32 = k32 * t32.steps, c16 = k16 * t16.steps;
+        const double csplit = rest ? 2.85 * main64.steps + (rest == 16 ? k16 : k32) * rest_plan.steps : 1e300;
+        shape = csplit <= c64 && csplit <= c32 && csplit <= c16 ? SPLIT : c64 <= c32 && c64 <= c16 ? ONE64 : c32 <= c16 ? ONE32 : ONE16;
+    }
+    if (shape == SPLIT) {
+        FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, main64, cv, ov, 0, 1)));
+        if (rest == 16) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, rest_plan, cv, ov, last_origin, 2)));
+        else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, rest_plan, cv, ov, last_origin, 2)));
+    } else if (shape == ONE64) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, t64, cv, ov)));
+    else if (shape == ONE32) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, t32, cv, ov)));
     else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, t16, cv, ov)));
     SIM_HIP(hipGetLastError());
     s->curv ^= 1;

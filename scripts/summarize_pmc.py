@@ -27,8 +27,6 @@ for n in map(int, sys.argv[2:]):
     for k, d in sorted(per.items()):
         f, nf = d.get("FETCH_SIZE", (0, 0)); w, _ = d.get("WRITE_SIZE", (0, 0))
         print(f"{k[:45]:45s} {nf:8d} {f:12.4g} {2 * f:12.4g} {w:12.4g} {(2 * f + w) / cells:10.2f}")
-        if "k_rb_rows2" in k and ", 1, 1>" in k and n % 4 == 0:
-            continue                                 # the narrow launch that serves the last few columns of wide rows
         if "k_rb_rows2" in k:                        # one launch = two full red-black sweeps
             out[f"{n}_pairs"] = {"kernel": k, "fetch_size_raw_bytes": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
                                  "hbm_bytes_per_cell": (2 * f + w) / cells, "algorithmic_bytes_per_cell": 100.0,

@@ -11,7 +11,7 @@ for nx, ny, nz in shapes:
     g = fs.FluidSim3D(nx, ny, nz, stop_mode=fs.STOP_FIXED, max_iters=1)
     g.sphere_influence(min(nx, ny, nz) / 10.0)
     out = []
-    for lanes in ("64", "32", "16", ""):
+    for lanes in ("64", "32", "16", "64+16", "64+32", ""):
         if lanes: os.environ["FSAMD_ROWS2_LANES_PER_ROW"] = lanes
         else: del os.environ["FSAMD_ROWS2_LANES_PER_ROW"]
         g.time_sweep_pairs(2)

@@ -10,11 +10,12 @@ from tests.util3d import assert_fields_equal, make_pair
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(20, 13, 11), (8, 3, 3), (4, 40, 5), (260, 40, 24), (64, 70, 50), (132, 18, 9), (30, 21, 17), (516, 20, 12),
+# (264 = a 256-column tile and 16 columns, 332 = one and 84: the shapes with a second launch for the last columns)
+SHAPES = [(264, 30, 12), (332, 18, 20), (20, 13, 11), (8, 3, 3), (4, 40, 5), (260, 40, 24), (64, 70, 50), (132, 18, 9), (30, 21, 17), (516, 20, 12),
           (96, 33, 140), (258, 19, 7), (72, 150, 10)]
 
 
-@pytest.mark.parametrize("lanes_per_row", [0, 64, 32, 16])
+@pytest.mark.parametrize("lanes_per_row", [0, 64, 32, 16, "64+16", "64+32"])
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_sweep_pairs_bit_exact(fsamd, monkeypatch, shape, dtype, lanes_per_row):

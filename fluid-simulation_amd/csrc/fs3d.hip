@@ -1112,6 +1112,8 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
     int next_check = check_after(resume_from);
     int it = resume_from;
     double metric = 0;
+    int last_it = -1;          // the last failed evaluation of this projection
+    double last_metric = 0;
     const bool pairs = pairs_possible(s);
     if (unchecked > 0) {
         FS_TRY(sweeps_n<T>(s, unchecked));
@@ -1184,6 +1186,16 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
             FS_TRY(residual<T>(s, &metric, nullptr, false));
             metric /= s->resid_dt;   // b = -div/dt (3_fluid/FluidSim.cpp:17), dx = rho = 1
             if (!(metric > c.tol)) break;
+            // Two failed evaluations give a decay rate, and Gauss-Seidel only slows down as it goes (the smooth error
+            // components outlive the others), so the rate promises at least n more sweeps: the next evaluation can wait
+            // for most of them.  Close to the tolerance n falls below 2 and every sweep is evaluated again, so the
+            // projection still stops on its first sweep at or below the tolerance.
+            if (adaptive && !deferred && last_it >= 0 && metric < last_metric && metric > 0) {
+                const double n = log(c.tol / metric) / (log(metric / last_metric) / (it - last_it));
+                if (n >= 2.5) next_check = std::max(next_check, (int)std::min<double>(c.max_iters, it + floor(0.8 * n)));
+            }
+            last_it = it;
+            last_metric = metric;
         }
         if (it >= c.max_iters) break;
     }

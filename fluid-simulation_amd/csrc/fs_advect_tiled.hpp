@@ -114,17 +114,17 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     // unconditional (from the own cell when the backtrace left the window) so that the reads of all samples of
     // a cell are in flight together; a sample outside the window then takes the general path of the direct
     // kernel: validity of every tap, clamped base address, global loads.
-    auto sample = [&](auto safe_tag, int f, T dx, T dy, T dz, int z, int gz, bool& oob) -> T {
+    auto sample = [&](auto safe_tag, int f, T dx, T dy, T dz, int gz, int slot_m, int slot_c, int slot_p, bool& oob) -> T {
         constexpr bool SAFE = decltype(safe_tag)::value;
         const T one = (T)1, zero = (T)0;
         const T px = (T)x - dx * t_step, py = (T)y - dy * t_step, pz = (T)gz - dz * t_step;
         const T bx = floor(px), by = floor(py), bz = floor(pz);
         const T fu = px - bx, fv = py - by, fw = pz - bz;
         const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
-        const bool far = !(fmax(fmax(fabs(bx), fabs(by)), fabs(bz)) < (T)8388608);
-        const int lzb = ibz - g.gz0;
-        const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(lzb - (z - R));
-        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R) && !far;
+        // (a backtrace beyond 2^23, which the reference treats apart (main.cpp:391-393), converts to an integer far
+        // outside the window and takes the general path below)
+        const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(ibz - (gz - R));
+        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
         FastTrace<T, OFF> tr;
         tr.far = false;
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
@@ -140,9 +140,11 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         uint32_t aw;   // ay * WX + ax (written out: the compiler would pick the 64-bit multiply-add, which is no faster)
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aw) : "v"(ay), "s"((uint32_t)WX), "v"(ax));
         const int a = in ? (int)aw : wl;
-        const int pl = in ? lzb : z;
-        const T* p0 = L + f * NPL * PS + (int)__umul24((uint32_t)(pl & (NPL - 1)), (uint32_t)PS) + a;
-        const T* p1 = L + f * NPL * PS + (int)__umul24((uint32_t)((pl + 1) & (NPL - 1)), (uint32_t)PS) + a;
+        // the lower plane of the taps is z-1 (az == 0) or z; the ring slots of z-1, z, z+1 are the same for the
+        // whole workgroup (slot_m, slot_c, slot_p: scalars)
+        const bool low = in && az == 0;
+        const T* p0 = L + f * NPL * PS + (low ? slot_m : slot_c) + a;
+        const T* p1 = L + f * NPL * PS + (low ? slot_c : slot_p) + a;
         t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[WX]; t.s[3] = p1[0];
         t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
         if (__builtin_expect(!in, 0)) {
@@ -197,8 +199,10 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
             const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
             bool oob_v = false, oob_d = false;
-            const T su = sample(safe_tag, 0, u_c, uy, uz, z, gz, oob_v), sv = sample(safe_tag, 1, vx, v_c, vz, z, gz, oob_v),
-                    sw = sample(safe_tag, 2, wx, wy, w_c, z, gz, oob_v);
+            const int slot_m = ((z - 1) & (NPL - 1)) * PS, slot_c = (z & (NPL - 1)) * PS, slot_p = ((z + 1) & (NPL - 1)) * PS;
+            const T su = sample(safe_tag, 0, u_c, uy, uz, gz, slot_m, slot_c, slot_p, oob_v),
+                    sv = sample(safe_tag, 1, vx, v_c, vz, gz, slot_m, slot_c, slot_p, oob_v),
+                    sw = sample(safe_tag, 2, wx, wy, w_c, gz, slot_m, slot_c, slot_p, oob_v);
             if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
             // main.cpp:284-289
             T uc, vc, wc;
@@ -207,7 +211,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             } else {
                 uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
             }
-            const T sd = sample(safe_tag, 3, uc, vc, wc, z, gz, oob_d);
+            const T sd = sample(safe_tag, 3, uc, vc, wc, gz, slot_m, slot_c, slot_p, oob_d);
             bool oob = fluid && oob_v;
             if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || oob_d; }
             if (SLAB && oob) *oob_flag = 1;

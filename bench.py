@@ -223,6 +223,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         a.gpus = world
 
+    # RCCL across processes needs dmabuf IPC on this driver stack (already exported on the boxes; kept here so that a
+    # bare shell gives the same run)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import fsamd_loader

@@ -63,3 +63,29 @@ def test_reflection_steps_with_paired_sweeps_equal_the_oracle(fsamd):
         g.advance(0.02)
         reflection_step_oracle(o, np.float32(0.02), 5)
         assert_fields_equal(o, g, what=f"reflection step {step} with 5 sweeps per projection")
+
+
+@pytest.mark.parametrize("lanes_per_row", [64, 16])
+def test_sweep_pairs_with_subnormal_huge_and_non_finite_values(fsamd, monkeypatch, lanes_per_row):
+    # the quotient of the visit is formed without the division instruction sequence: values of every magnitude, zeros of
+    # both signs, infinities and NaNs must still come out as the oracle's IEEE division gives them
+    monkeypatch.setenv("FSAMD_ROWS2_LANES_PER_ROW", str(lanes_per_row))
+    nx, ny, nz = 72, 21, 14
+    o, g = make_pair(fsamd, nx, ny, nz, seed=3, stop_mode=fsamd.STOP_FIXED, max_iters=1)
+    rng = np.random.default_rng(8)
+    for k in range(3):
+        mag = np.exp2(rng.integers(-149, 100, size=(nz, ny, nx)).astype(np.float64))
+        f = (mag * rng.choice([-1.0, 1.0], size=mag.shape) * rng.uniform(1.0, 2.0, size=mag.shape)).astype(np.float32)
+        f[rng.random(f.shape) < 0.02] = 0.0
+        f[rng.random(f.shape) < 0.01] = -0.0
+        f[rng.random(f.shape) < 0.002] = np.inf
+        f[rng.random(f.shape) < 0.002] = np.nan
+        o.field(k)[...] = f
+        g.set_field(k, f)
+    with np.errstate(all="ignore"):
+        for n in (2, 4):
+            g.sweeps(n)
+            o.project_rb(stop_mode=0, max_iter=n)
+            for k in range(3):
+                a, b = o.field(k), g.get_field(k)
+                assert np.array_equal(a, b, equal_nan=True), (n, k, int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum()))

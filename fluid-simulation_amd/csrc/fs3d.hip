@@ -61,6 +61,7 @@ struct Part {
     bool mg_weights_ok = false;
     uint8_t* cells = nullptr;
     uint8_t* flags = nullptr;
+    uint8_t* vflags = nullptr;   // visit bytes of the register-resident sweeps (k_build_flags)
     void* recv_lo = nullptr;   // staging for the interface w plane from the lower / upper rank
     void* recv_hi = nullptr;
     double* partials = nullptr;
@@ -157,7 +158,7 @@ void free_parts(fs3d_sim* s) {
         for (int k = 0; k < 3; ++k) (void)hipFree(p.tmp[k]);
         for (int k = 0; k < 4; ++k) (void)hipFree(p.mc[k]);
         for (auto& l : p.mg) for (void* a : l.a) (void)hipFree(a);
-        (void)hipFree(p.cells); (void)hipFree(p.flags);
+        (void)hipFree(p.cells); (void)hipFree(p.flags); (void)hipFree(p.vflags);
         (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
         (void)hipFree(p.partials);
         (void)hipFree(p.adv_part);
@@ -189,6 +190,7 @@ int alloc_parts(fs3d_sim* s) {
         for (int q = 0; q < 3; ++q) SIM_HIP(hipMalloc(&p.tmp[q], p.n * s->esz));
         SIM_HIP(hipMalloc((void**)&p.cells, p.n));
         SIM_HIP(hipMalloc((void**)&p.flags, p.n));
+        SIM_HIP(hipMalloc((void**)&p.vflags, p.n));
         SIM_HIP(hipMalloc((void**)&p.partials, sizeof(double) * 2 * kReduceBlocks));
         if (p.H) {
             SIM_HIP(hipMalloc(&p.recv_lo, (size_t)p.g.sz * s->esz));
@@ -327,7 +329,7 @@ int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t
 }
 
 void* base_field_cur(fs3d_sim* s, Part& p, int k) { return p.f[k < 3 ? s->curv : s->curd][k]; }
-void* base_flags(fs3d_sim*, Part& p, int) { return p.flags; }
+void* base_flags(fs3d_sim*, Part& p, int which) { return which == 0 ? p.flags : p.vflags; }
 void* base_tmp(fs3d_sim*, Part& p, int k) { return p.tmp[k]; }
 void* base_cells(fs3d_sim*, Part& p, int) { return p.cells; }
 
@@ -391,11 +393,11 @@ int refresh_flags(fs3d_sim* s) {
     FS_TRY(exchange_halos(s, {{base_cells, 0, 1}}));
     for (Part& p : s->parts) {
         dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
-        hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, p.g, p.cells, p.flags);
+        hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, p.g, p.cells, p.flags, p.vflags);
     }
     SIM_HIP(hipGetLastError());
     // the flags of a halo plane depend on cells beyond the halo: take them from the plane's owner
-    FS_TRY(exchange_halos(s, {{base_flags, 0, 1}}));
+    FS_TRY(exchange_halos(s, {{base_flags, 0, 1}, {base_flags, 1, 1}}));
     s->cells_dirty = false;
     for (Part& p : s->parts) p.mg_weights_ok = false;
     return FS_OK;
@@ -599,7 +601,7 @@ int launch_rows_tiles(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int 
     }
     dim3 b(64, rows, 1), g(ntx * nty * zgroups, 1, 1);
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), st, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
-                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, r, ntx, nty, rows, xbase, xedges);
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, p.vflags, (T)s->cfg.omega, r, ntx, nty, rows, xbase, xedges);
     return FS_OK;
 }
 
@@ -690,7 +692,7 @@ int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov, int xbas
     Part& p = s->parts[0];
     dim3 b(64, t.waves, 1), g(t.ntx * t.nty * t.zgroups, 1, 1);
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
-                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.flags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, xbase, xedges);
+                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.vflags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, xbase, xedges);
     return FS_OK;
 }
 
@@ -2475,7 +2477,7 @@ int residual_noalloc(int nx, int ny, int nz, const void* u, const void* v, const
     // every kernel below writes all of what the next one reads (flags of every cell, one partial pair per
     // workgroup, the combined pair), so nothing has to start at zero
     dim3 b(64, 4, 1), gf(div_up(nx, 64), div_up(ny, 4), nz);
-    hipLaunchKernelGGL(k_build_flags, gf, b, 0, st, g, cells, flags);
+    hipLaunchKernelGGL(k_build_flags, gf, b, 0, st, g, cells, flags, (uint8_t*)nullptr);
     hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, st, g, (const T*)u, (const T*)v, (const T*)w,
                        (const uint8_t*)flags, 1, nz - 1, partials, (T*)nullptr);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, (const double*)partials, kReduceBlocks, pair);

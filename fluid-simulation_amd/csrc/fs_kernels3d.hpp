@@ -39,7 +39,17 @@ __device__ __forceinline__ int64_t gidx(const Grid& g, int x, int y, int z) {
 // ---------------------------------------------------------------------------
 // cell types -> flags.  Planes outside the global domain and neighbours outside
 // the local array count as Object.
-__global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t* __restrict__ flags) {
+//
+// vflags (optional) receives the "visit byte" of each cell, which is all a Gauss-Seidel visit
+// (main.cpp:198-233) needs of the mask: bits 0..5 (FL_XM..FL_ZP) = the faces the visit moves - none of an
+// Object cell or of a cell without Fluid neighbours (:199, :221), the high faces towards Fluid neighbours,
+// the low ones only if the cell is Fluid itself (:227-232) - and bits 6..7 = the number of Fluid neighbours
+// that count in the divisor (:222) without their face being moved (the low-side neighbours of a cell that
+// is not Fluid itself).
+__device__ __forceinline__ int visit_divisor(uint32_t vb) { return __popc(vb & FL_NBR) + (int)(vb >> 6); }
+
+__global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t* __restrict__ flags,
+                              uint8_t* __restrict__ vflags) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int z = blockIdx.z;
@@ -57,6 +67,12 @@ __global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t
     if (type_at(x, y + 1, z) == 0u) f |= FL_YP;
     if (type_at(x, y, z - 1) == 0u) f |= FL_ZM;
     if (type_at(x, y, z + 1) == 0u) f |= FL_ZP;
+    if (vflags) {
+        constexpr uint32_t low = FL_XM | FL_YM | FL_ZM;
+        uint32_t vb = 0;
+        if (self != 1u) vb = self == 0u ? f : ((f & ~low) | ((uint32_t)__popc(f & low) << 6));
+        vflags[i] = (uint8_t)vb;
+    }
     if (self == 0u) f |= FL_SELF_FLUID;
     if (self == 1u) f |= FL_SELF_OBJECT;
     flags[i] = (uint8_t)f;

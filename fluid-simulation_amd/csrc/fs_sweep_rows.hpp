@@ -35,8 +35,48 @@ template <typename T, int NQ, int NSEG>
 struct RowPlane {            // what a lane holds of one z-plane: NQ = NSEG*CP column pairs
     T u[NQ][2];
     T w[NQ][2];
-    uint32_t f[NSEG];        // flag bytes of the lane's 2*CP columns of a segment, column k in bits 8k..8k+7
+    uint32_t f[NSEG];        // visit bytes (k_build_flags) of the lane's 2*CP columns of a segment, column k in bits 8k..8k+7
 };
+
+// ---- pieces of a cell visit shared by the register-resident sweep kernels -----------------------------------
+// All ones where bit BIT of w is set: one signed bit-field extract.  (Written as shifts the compiler turns it back
+// into a test, a compare and a conditional move, which is what this is here to avoid.)
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask(uint32_t w) {
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(BIT));
+    return r;
+}
+// m ? a : b, bit by bit: one bit-field insert
+__device__ __forceinline__ float pick(uint32_t m, float a, float b) {
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// 1 / divisor for each of the 256 visit bytes, in double: the table of visit_quotient(), filled by the workgroup.
+constexpr size_t kRcpBytes = 256 * sizeof(double);
+__device__ __forceinline__ void fill_reciprocals(double* rcp, int tid, int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) rcp[i] = 1.0 / (double)max(1, visit_divisor((uint32_t)i));
+}
+// div / (number of Fluid neighbours), the division of main.cpp:222, correctly rounded.  In single precision it is
+// formed as float(double(div) * rcp): the double product is within 2^-52 of the quotient, and a quotient of a float by
+// 1..6 is either a float itself or at least 2^-27 (relative) away from the nearest point where rounding to float
+// changes, so the rounding to float sees the same side as the exact quotient does; zeros, infinities, NaNs and
+// subnormal results come out as IEEE division gives them (all 2^32 dividends x 6 divisors compared on the host).
+// Five instructions instead of the fifteen of the division sequence.  vb = the cell's visit byte (0: the cell is not
+// relaxed and the result is unused).
+template <typename T>
+__device__ __forceinline__ T visit_quotient(T div, uint32_t vb, const double* rcp) {
+    if constexpr (sizeof(T) == 4) return (T)((double)div * rcp[vb & 0xffu]);
+    else return div / (T)max(1, visit_divisor(vb & 0xffu));
+}
 
 template <typename T, int NSEG, int CP>
 struct RowsCfg {
@@ -45,22 +85,29 @@ struct RowsCfg {
     static constexpr int W = SEGW * NSEG;
     static constexpr int NQ = NSEG * CP;
     static constexpr int NPV = 2;           // v planes in LDS: the planes of the two colours of a step
-    static constexpr size_t lds_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
+    static constexpr size_t v_bytes() { return (size_t)NPV * RY * W * sizeof(T); }
+    static constexpr size_t lds_bytes() { return v_bytes() + kRcpBytes; }
 };
 
+// Variants whose lanes hold at most 8 bytes of a row per plane fit 64 registers - two workgroups per CU - with the
+// compare-and-move form of the visit and the division instruction sequence (LEAN); the wider ones have 128 registers
+// anyway and take the shorter select form.
 template <typename T, int NSEG, int CP>
 __global__ void __launch_bounds__(1024, (NSEG * CP * sizeof(T) <= 8 ? 8 : 4))
 k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
-          T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
-          FusedRanges r, int ntx, int nty, int rows, int xbase, int xedges) {
+          T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags,
+          const uint8_t* __restrict__ vflags, T omega, FusedRanges r, int ntx, int nty, int rows, int xbase, int xedges) {
     using C = RowsCfg<T, NSEG, CP>;
     constexpr int NQ = C::NQ;
+    constexpr bool LEAN = NSEG * CP * sizeof(T) <= 8;
     using VecT = Vec<T, 2 * CP>;
     using FlagWord = typename std::conditional<CP == 1, uint16_t, uint32_t>::type;   // the 2*CP flag bytes of a lane
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // [NPV][rows][W]; a row holds, per pair index q, the even columns of all lanes, then the odd ones:
     // the active cells of a row all have the same x parity, so a wave reads consecutive words
     T* sv = reinterpret_cast<T*>(lds_raw);
+    double* rcp = reinterpret_cast<double*>(lds_raw + C::v_bytes());
+    if constexpr (!LEAN) fill_reciprocals(rcp, threadIdx.y * 64 + threadIdx.x, blockDim.y * 64);   // (the barrier of the first step comes before its first use)
 
     const int lane = threadIdx.x, ry = threadIdx.y;
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Renumber them so that the
@@ -99,6 +146,15 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
             pair_core[sg * CP + j] = row_core && x + 2 * j >= cx_lo && x + 2 * j < cx_hi;
     }
 
+    // cells of this lane that are ever visited: not those of the last row of the tile (the v of the row above is not
+    // held) nor the last column of the tile (the u of the column after it is not held)
+    uint32_t keep[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        keep[sg] = ry < rows - 1 ? 0xffffffffu : 0u;
+        if (sg == NSEG - 1 && lane == 63) keep[sg] &= CP == 1 ? 0x00ffu : 0x00ffffffu;
+    }
+
     RowPlane<T, NQ, NSEG> P0, P1, P2, P3;
     VecT vst[NSEG];
 
@@ -109,16 +165,17 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
             const bool in = pin && seg_in[sg];
             const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
             VecT pu, pv;
-            uint32_t fw = CP == 1 ? 0x8080u : 0x80808080u;   // FL_SELF_OBJECT in every byte
+            // columns outside the grid are not visited: FL_SELF_OBJECT in every flag byte, or visit bytes of zero
+            uint32_t fw = LEAN ? (CP == 1 ? 0x8080u : 0x80808080u) : 0u;
             static_assert(FL_SELF_OBJECT == 0x80u, "filler for columns outside the grid");
 #pragma unroll
             for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; }
             if (in) {
                 pu = *reinterpret_cast<const VecT*>(ui + i);
                 pv = *reinterpret_cast<const VecT*>(vi + i);
-                fw = *reinterpret_cast<const FlagWord*>(flags + i);
+                fw = *reinterpret_cast<const FlagWord*>((LEAN ? flags : vflags) + i);
             }
-            X.f[sg] = fw;
+            X.f[sg] = LEAN ? fw : fw & keep[sg];
 #pragma unroll
             for (int j = 0; j < CP; ++j) { X.u[sg * CP + j][0] = pu.e[2 * j]; X.u[sg * CP + j][1] = pu.e[2 * j + 1]; }
             vst[sg] = pv;
@@ -150,8 +207,83 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
                 row[vpos(sg * CP + j, 1)] = vst[sg].e[2 * j + 1];
             }
     };
-    // One colour on plane p.  X holds plane p, Y plane p+1 (for the high-z faces).
+    // One colour on plane p.  X holds plane p, Y plane p+1 (for the high-z faces).  A cell's visit byte says which
+    // of its faces move; every face is rewritten, with its old value where the byte says so: in single precision a
+    // bit-field extract and a bitwise select per face, no tests, compares or conditional moves.
     auto relax = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
+        const int c = (colour + xr0 + y + p + g.gz0) & 1;   // the active column of every pair of this row
+        T* v0row = vrow(p, ry);
+        T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
+        T send[NQ];
+        auto visit = [&](auto colour_of_pair) {
+            constexpr int cc = decltype(colour_of_pair)::value;
+            static_for<NQ>([&](auto column_pair) {
+                constexpr int q = decltype(column_pair)::value, sg = q / CP, j = q % CP, sh = 16 * j + 8 * cc;
+                const uint32_t vw = X.f[sg];
+                const T u0 = X.u[q][cc];
+                // the high-x face of the pair's second column is the low-x face of the next pair: the lane's own
+                // next pair, or the first pair of the segment in the next lane (the last column of a tile gets a
+                // foreign value: it is never updated)
+                T u1;
+                if constexpr (cc == 0) u1 = X.u[q][1];
+                else if constexpr (j + 1 < CP) u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
+                else {
+                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);
+                    if constexpr (sg + 1 < NSEG) {
+                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], 0, 64);
+                        if (lane == 63) u1 = wrap;
+                    }
+                }
+                const int a = vpos(q, cc);
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[q][cc], w1 = Y.w[q][cc];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                const T dd = omega * visit_quotient(div, vw >> sh, rcp);   // (x * 1 is x: omega == 1 needs no test)
+                if constexpr (sizeof(T) == 4) {
+                    v0row[a] = pick(bit_mask<sh + 2>(vw), v0 + dd, v0);
+                    v1row[a] = pick(bit_mask<sh + 3>(vw), v1 - dd, v1);
+                    X.u[q][cc] = pick(bit_mask<sh>(vw), u0 + dd, u0);
+                    if constexpr (cc == 0) X.u[q][1] = pick(bit_mask<sh + 1>(vw), u1 - dd, u1);
+                    else send[q] = __uint_as_float(__float_as_uint(dd) & bit_mask<sh + 1>(vw));
+                    X.w[q][cc] = pick(bit_mask<sh + 4>(vw), w0 + dd, w0);
+                    Y.w[q][cc] = pick(bit_mask<sh + 5>(vw), w1 - dd, w1);
+                } else {
+                    const uint32_t vb = vw >> sh;
+                    if (vb & FL_XM) X.u[q][cc] = u0 + dd;
+                    if constexpr (cc == 0) { if (vb & FL_XP) X.u[q][1] = u1 - dd; }
+                    else send[q] = (vb & FL_XP) ? dd : (T)0;
+                    if (vb & FL_YM) v0row[a] = v0 + dd;
+                    if (vb & FL_YP) v1row[a] = v1 - dd;
+                    if (vb & FL_ZM) X.w[q][cc] = w0 + dd;
+                    if (vb & FL_ZP) Y.w[q][cc] = w1 - dd;
+                }
+            });
+        };
+        if (c == 0) visit(std::integral_constant<int, 0>{});
+        else {
+            visit(std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {   // deliver -dd to the low-x face of the pair on the right
+                const int sg = q / CP, j = q % CP;
+                T got;
+                bool any = true;
+                if (j > 0) {
+                    got = send[q > 0 ? q - 1 : 0];
+                } else {
+                    got = __shfl_up(send[sg * CP + CP - 1], 1, 64);
+                    any = lane > 0;
+                    if (sg > 0) {
+                        const T wrap = __shfl(send[(sg > 0 ? sg : 1) * CP - 1], 63, 64);
+                        if (lane == 0) { got = wrap; any = true; }
+                    }
+                }
+                if (any && got != (T)0) X.u[q][0] = X.u[q][0] - got;
+            }
+        }
+    };
+    // The same visit on the flag bytes themselves, as compares and conditional moves with the division instruction
+    // sequence: the form that fits 64 registers (LEAN variants).
+    auto relax_lean = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
         const int c = (colour + xr0 + y + p + g.gz0) & 1;   // the active column of every pair of this row
         T* v0row = vrow(p, ry);
         T* v1row = vrow(p, ry < rows - 1 ? ry + 1 : ry);
@@ -278,8 +410,12 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
         load_uf(N, t + 1);                                                      \
         load_w(F, t + 2);                                                       \
         __syncthreads();                                                        \
-        if (t >= s0b && t < s0e) relax(Cc, N, t, 0);                            \
-        if (t - 1 >= s1b && t - 1 < s1e) relax(M, Cc, t - 1, 1);                \
+        if (t >= s0b && t < s0e) {                                              \
+            if constexpr (LEAN) relax_lean(Cc, N, t, 0); else relax(Cc, N, t, 0); \
+        }                                                                       \
+        if (t - 1 >= s1b && t - 1 < s1e) {                                      \
+            if constexpr (LEAN) relax_lean(M, Cc, t - 1, 1); else relax(M, Cc, t - 1, 1); \
+        }                                                                       \
         __syncthreads();                                                        \
         if (t - 1 >= c0 && t - 1 < c1) store_plane(M, t - 1);                   \
         ++t;                                                                    \

@@ -41,40 +41,13 @@ struct Rows2Cfg {
     static constexpr int NPV = 5;           // v planes in LDS: one per phase of a step and the plane being stored
     static constexpr int S = 4;             // rings of a tile that go stale (one per half-sweep)
     static constexpr size_t v_bytes() { return (size_t)NPV * WAVES * 2 * NQ * 64 * sizeof(T); }
-    static constexpr size_t lds_bytes() { return v_bytes() + 64 * sizeof(double); }   // + the reciprocals of quotient()
+    static constexpr size_t lds_bytes() { return v_bytes() + kRcpBytes; }   // + the reciprocals of visit_quotient()
 };
-
-template <typename T, int NQ, int NSEG>
-struct PairPlane : RowPlane<T, NQ, NSEG> {
-    uint32_t upd[NSEG];      // per column one byte like f: bit k set = a visit of the cell moves face k (FL_XM .. FL_ZP)
-};
-
-// All ones where bit BIT of w is set: one signed bit-field extract.  (Written as shifts the compiler turns it back
-// into a test, a compare and a conditional move, which is what this is here to avoid.)
-template <int BIT>
-__device__ __forceinline__ uint32_t bit_mask(uint32_t w) {
-    uint32_t r;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(BIT));
-    return r;
-}
-// m ? a : b, bit by bit: one bit-field insert
-__device__ __forceinline__ float pick(uint32_t m, float a, float b) {
-    float r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-    return r;
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 
 template <typename T, int NSEG, int CP, int LPR>
 __global__ void __launch_bounds__(1024, 4)
 k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
-           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ flags, T omega,
+           T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ vflags, T omega,
            int zb, int ze, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
     constexpr int NQ = C::NQ, S = C::S;
@@ -83,9 +56,8 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* sv = reinterpret_cast<T*>(lds_raw);   // [NPV][waves][2 * NQ][64]: a wave's lanes side by side, whatever rows they hold
 
-    // 1 / (number of Fluid neighbours) for each of the 64 neighbour masks, in double (see quotient())
     double* rcp = reinterpret_cast<double*>(lds_raw + C::v_bytes());
-    if (threadIdx.y == 0) rcp[threadIdx.x] = 1.0 / (double)max(1, __popc(threadIdx.x));
+    fill_reciprocals(rcp, threadIdx.y * 64 + threadIdx.x, blockDim.y * 64);   // (the barrier of the first step comes before its first use)
 
     const int lane = threadIdx.x, ry = threadIdx.y, waves = blockDim.y;
     const int lx = lane & (LPR - 1), sub = lane / LPR;
@@ -143,39 +115,31 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
         if (sg == NSEG - 1 && lx == LPR - 1) keep[sg] &= CP == 1 ? 0x00ffu : 0x00ffffffu;
     }
 
-    PairPlane<T, NQ, NSEG> A, B, Cc, D, E, F;   // planes t-3, t-2, t-1, t, t+1 (u, flags; w since a step earlier), t+2 (w)
+    RowPlane<T, NQ, NSEG> A, B, Cc, D, E, F;   // planes t-3, t-2, t-1, t, t+1 (u, flags; w since a step earlier), t+2 (w)
     VecT vst[NSEG];
 
-    auto load_uf = [&](PairPlane<T, NQ, NSEG>& X, int p) {
+    auto load_uf = [&](RowPlane<T, NQ, NSEG>& X, int p) {
         const bool pin = p >= lb && p < le;
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
             const bool in = pin && seg_in[sg];
             const int64_t i = in ? (int64_t)p * g.sz + rowoff + sg * C::SEGW : 0;
             VecT pu, pv;
-            uint32_t fw = CP == 1 ? 0x8080u : 0x80808080u;   // FL_SELF_OBJECT in every byte
+            uint32_t fw = 0;   // columns outside the grid are not visited
 #pragma unroll
             for (int k = 0; k < 2 * CP; ++k) { pu.e[k] = 0; pv.e[k] = 0; }
             if (in) {
                 pu = *reinterpret_cast<const VecT*>(ui + i);
                 pv = *reinterpret_cast<const VecT*>(vi + i);
-                fw = *reinterpret_cast<const FlagWord*>(flags + i);
+                fw = *reinterpret_cast<const FlagWord*>(vflags + i);
             }
-            X.f[sg] = fw;
-            if constexpr (sizeof(T) == 4) {
-                // which faces a visit moves (main.cpp:199, :221-230): none of an Object cell, not the low ones of a cell
-                // that is not Fluid itself, only those towards Fluid neighbours; none in the last row and column of a tile
-                constexpr uint32_t ones = CP == 1 ? 0x0101u : 0x01010101u;
-                const uint32_t obj = (fw >> 7) & ones, notself = (~fw >> 6) & ones;
-                const uint32_t low = notself | (notself << 2) | (notself << 4);   // FL_XM | FL_YM | FL_ZM of those cells
-                X.upd[sg] = fw & (ones * 0x3fu) & ~((obj << 6) - obj) & ~low & keep[sg];
-            }
+            X.f[sg] = fw & keep[sg];
 #pragma unroll
             for (int j = 0; j < CP; ++j) { X.u[sg * CP + j][0] = pu.e[2 * j]; X.u[sg * CP + j][1] = pu.e[2 * j + 1]; }
             vst[sg] = pv;
         }
     };
-    auto load_w = [&](PairPlane<T, NQ, NSEG>& X, int p) {
+    auto load_w = [&](RowPlane<T, NQ, NSEG>& X, int p) {
         const bool pin = p >= lb && p < le;
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
@@ -201,19 +165,8 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                 row[vpos(sg * CP + j, 1)] = vst[sg].e[2 * j + 1];
             }
     };
-    // div / (number of Fluid neighbours), the division of main.cpp:222, correctly rounded.  In single precision it is
-    // formed as float(double(div) * rcp): the double product is within 2^-52 of the quotient, and a quotient of a float by
-    // 1..6 is either a float itself or at least 2^-27 (relative) away from the nearest point where rounding to float
-    // changes, so the rounding to float sees the same side as the exact quotient does; zeros, infinities, NaNs and
-    // subnormal results come out as IEEE division gives them (all 2^32 dividends x 6 divisors compared on the host).
-    // Five instructions instead of the fifteen of the division sequence, in the kernel's critical resource.
-    // The result is unused where the cell is not relaxed.
-    auto quotient = [&](T div, uint32_t fl, bool ok) -> T {
-        if constexpr (sizeof(T) == 4) { (void)ok; return (T)((double)div * rcp[fl & FL_NBR]); }
-        else return div / (T)(ok ? __popc(fl & FL_NBR) : 1);
-    };
     // One colour on plane p (X = plane p, Y = plane p+1): the visit of k_rb_rows.
-    auto relax = [&](PairPlane<T, NQ, NSEG>& X, PairPlane<T, NQ, NSEG>& Y, int p, int colour) {
+    auto relax = [&](RowPlane<T, NQ, NSEG>& X, RowPlane<T, NQ, NSEG>& Y, int p, int colour) {
         const int c = (colour + xr0 + y + p + g.gz0) & 1;
         T* v0row = vrow(p, ry);
         // the row above: the same lanes of the next wave (from an even wave); from an odd wave the next row of the
@@ -224,8 +177,51 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                    : sub < C::RPW - 1 ? vrow(p, ry - 1) + LPR
                                       : vrow(p, ry + 1) - (C::RPW - 1) * LPR;
         T send[NQ];
-        // what the second colour's visits took from the u face they share with the column after them
-        auto receive = [&]() {
+        auto visit = [&](auto colour_of_pair) {
+            constexpr int cc = decltype(colour_of_pair)::value;
+            static_for<NQ>([&](auto column_pair) {
+                constexpr int q = decltype(column_pair)::value, sg = q / CP, j = q % CP, sh = 16 * j + 8 * cc;
+                const uint32_t vw = X.f[sg];
+                const T u0 = X.u[q][cc];
+                T u1;
+                if constexpr (cc == 0) u1 = X.u[q][1];
+                else if constexpr (j + 1 < CP) u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
+                else {
+                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);   // (the last column of a tile gets a foreign value: it is never updated)
+                    if constexpr (sg + 1 < NSEG) {
+                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], lane & ~(LPR - 1), 64);
+                        if (lx == LPR - 1) u1 = wrap;
+                    }
+                }
+                const int a = vpos(q, cc);
+                const T v0 = v0row[a], v1 = v1row[a];
+                const T w0 = X.w[q][cc], w1 = Y.w[q][cc];
+                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
+                const T dd = omega * visit_quotient(div, vw >> sh, rcp);   // (x * 1 is x: omega == 1 needs no test)
+                if constexpr (sizeof(T) == 4) {
+                    v0row[a] = pick(bit_mask<sh + 2>(vw), v0 + dd, v0);
+                    v1row[a] = pick(bit_mask<sh + 3>(vw), v1 - dd, v1);
+                    X.u[q][cc] = pick(bit_mask<sh>(vw), u0 + dd, u0);
+                    if constexpr (cc == 0) X.u[q][1] = pick(bit_mask<sh + 1>(vw), u1 - dd, u1);
+                    else send[q] = __uint_as_float(__float_as_uint(dd) & bit_mask<sh + 1>(vw));
+                    X.w[q][cc] = pick(bit_mask<sh + 4>(vw), w0 + dd, w0);
+                    Y.w[q][cc] = pick(bit_mask<sh + 5>(vw), w1 - dd, w1);
+                } else {
+                    const uint32_t vb = vw >> sh;
+                    if (vb & FL_XM) X.u[q][cc] = u0 + dd;
+                    if constexpr (cc == 0) { if (vb & FL_XP) X.u[q][1] = u1 - dd; }
+                    else send[q] = (vb & FL_XP) ? dd : (T)0;
+                    if (vb & FL_YM) v0row[a] = v0 + dd;
+                    if (vb & FL_YP) v1row[a] = v1 - dd;
+                    if (vb & FL_ZM) X.w[q][cc] = w0 + dd;
+                    if (vb & FL_ZP) Y.w[q][cc] = w1 - dd;
+                }
+            });
+        };
+        if (c == 0) visit(std::integral_constant<int, 0>{});
+        else {
+            visit(std::integral_constant<int, 1>{});
+            // what the second colour's visits took from the u face they share with the column after them
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int sg = q / CP, j = q % CP;
@@ -243,100 +239,9 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                 }
                 if (any && got != (T)0) X.u[q][0] = X.u[q][0] - got;
             }
-        };
-        // Single precision: every face is rewritten, with its old value where the update mask says so (a bit-field
-        // extract and a bitwise select per face instead of tests, compares and conditional moves).
-        auto visit32 = [&](auto colour_of_pair) {
-            constexpr int cc = decltype(colour_of_pair)::value;
-            static_for<NQ>([&](auto column_pair) {
-                constexpr int q = decltype(column_pair)::value, sg = q / CP, j = q % CP, sh = 16 * j + 8 * cc;
-                const uint32_t up = X.upd[sg];
-                const T u0 = X.u[q][cc];
-                T u1;
-                if constexpr (cc == 0) u1 = X.u[q][1];
-                else if constexpr (j + 1 < CP) u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
-                else {
-                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);   // (the last column of a tile gets a foreign value: it is never updated)
-                    if constexpr (sg + 1 < NSEG) {
-                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], lane & ~(LPR - 1), 64);
-                        if (lx == LPR - 1) u1 = wrap;
-                    }
-                }
-                const int a = vpos(q, cc);
-                const T v0 = v0row[a], v1 = v1row[a];
-                const T w0 = X.w[q][cc], w1 = Y.w[q][cc];
-                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
-                const T dd = omega * quotient(div, X.f[sg] >> sh, true);   // (x * 1 is x: omega == 1 needs no test)
-                v0row[a] = pick(bit_mask<sh + 2>(up), v0 + dd, v0);
-                v1row[a] = pick(bit_mask<sh + 3>(up), v1 - dd, v1);
-                X.u[q][cc] = pick(bit_mask<sh>(up), u0 + dd, u0);
-                if constexpr (cc == 0) X.u[q][1] = pick(bit_mask<sh + 1>(up), u1 - dd, u1);
-                else send[q] = __uint_as_float(__float_as_uint(dd) & bit_mask<sh + 1>(up));
-                X.w[q][cc] = pick(bit_mask<sh + 4>(up), w0 + dd, w0);
-                Y.w[q][cc] = pick(bit_mask<sh + 5>(up), w1 - dd, w1);
-            });
-        };
-        if constexpr (sizeof(T) == 4) {
-            if (c == 0) visit32(std::integral_constant<int, 0>{});
-            else { visit32(std::integral_constant<int, 1>{}); receive(); }
-        } else if (c == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const uint32_t fl = (X.f[q / CP] >> (16 * (q % CP))) & 0xffu;
-                const bool ok = row_ok && relaxes(fl);
-                const int a = vpos(q, 0);
-                const T u0 = X.u[q][0], u1 = X.u[q][1];
-                const T v0 = v0row[a], v1 = v1row[a];
-                const T w0 = X.w[q][0], w1 = Y.w[q][0];
-                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
-                T dd = quotient(div, fl, ok);
-                dd = omega * dd;   // (the reference multiplies only when omega != 1: x * 1 is x)
-                const bool self = fl & FL_SELF_FLUID;
-                if (ok && (fl & FL_XM) && self) X.u[q][0] = u0 + dd;
-                if (ok && (fl & FL_XP)) X.u[q][1] = u1 - dd;
-                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
-                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
-                if (ok && (fl & FL_ZM) && self) X.w[q][0] = w0 + dd;
-                if (ok && (fl & FL_ZP)) Y.w[q][0] = w1 - dd;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int sg = q / CP, j = q % CP;
-                const uint32_t fl = (X.f[sg] >> (16 * j + 8)) & 0xffu;
-                T u1;
-                bool have_hi = true;
-                if (j + 1 < CP) {
-                    u1 = X.u[q + 1 < NQ ? q + 1 : q][0];
-                } else {
-                    u1 = __shfl_down(X.u[sg * CP][0], 1, 64);
-                    if (sg + 1 < NSEG) {
-                        const T wrap = __shfl(X.u[(sg + 1 < NSEG ? sg + 1 : sg) * CP][0], lane & ~(LPR - 1), 64);
-                        if (lx == LPR - 1) u1 = wrap;
-                    } else {
-                        have_hi = lx < LPR - 1;
-                    }
-                }
-                const bool ok = row_ok && have_hi && relaxes(fl);
-                const int a = vpos(q, 1);
-                const T u0 = X.u[q][1];
-                const T v0 = v0row[a], v1 = v1row[a];
-                const T w0 = X.w[q][1], w1 = Y.w[q][1];
-                const T div = (u1 - u0) + (v1 - v0) + (w1 - w0);
-                T dd = quotient(div, fl, ok);
-                dd = omega * dd;   // (the reference multiplies only when omega != 1: x * 1 is x)
-                const bool self = fl & FL_SELF_FLUID;
-                if (ok && (fl & FL_XM) && self) X.u[q][1] = u0 + dd;
-                send[q] = (ok && (fl & FL_XP)) ? dd : (T)0;
-                if (ok && (fl & FL_YM) && self) v0row[a] = v0 + dd;
-                if (ok && (fl & FL_YP)) v1row[a] = v1 - dd;
-                if (ok && (fl & FL_ZM) && self) X.w[q][1] = w0 + dd;
-                if (ok && (fl & FL_ZP)) Y.w[q][1] = w1 - dd;
-            }
-            receive();
         }
     };
-    auto store_plane = [&](PairPlane<T, NQ, NSEG>& X, int p) {
+    auto store_plane = [&](RowPlane<T, NQ, NSEG>& X, int p) {
         const T* row = vrow(p, ry);
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
@@ -376,7 +281,7 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     // moved at the start of the NEXT step, so that a fetch has a whole step to arrive.  A plane is stored one step
     // after its last visit: the barrier that opens a step is then the only one (it also separates that visit, which
     // other waves made to this wave's v row, from the store).
-    PairPlane<T, NQ, NSEG> Z;
+    RowPlane<T, NQ, NSEG> Z;
     load_uf(Z, -1); load_uf(A, -1); load_uf(B, -1); load_uf(Cc, -1); load_uf(D, -1); load_uf(E, -1); load_uf(F, -1);
     load_w(Z, -1); load_w(A, -1); load_w(B, -1); load_w(Cc, -1); load_w(D, -1); load_w(E, -1);
     load_w(F, lb);   // the step before the first one "fetched" the w of plane lb

@@ -15,11 +15,11 @@ timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 echo "stats default done"
 for n in 256 512; do   # one size per run, so that the per-kernel averages are not mixed
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$n -- \
-      python3 $R/bench.py --no-cpu-baseline --no-multigrid-leg --no-512-leg --n $n > $OUT/bench${n}_line_under_rocprof.json
+      python3 $R/bench.py --no-cpu-baseline --no-multigrid-leg --no-512-leg --no-steady-leg --n $n > $OUT/bench${n}_line_under_rocprof.json
   echo "stats $n done"
 done
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_mg256 -- \
-    python3 $R/bench.py --no-cpu-baseline --no-512-leg --solver multigrid > $OUT/bench_mg256_line_under_rocprof.json
+    python3 $R/bench.py --no-cpu-baseline --no-512-leg --no-steady-leg --solver multigrid > $OUT/bench_mg256_line_under_rocprof.json
 echo "stats multigrid done"
 for n in 256 512; do
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -653,7 +653,8 @@ int launch_one_pass_sweep(fs3d_sim* s) {
 
 // Two sweeps in one pass over HBM (fs_sweep_rows2.hpp): single domain, even nx, the register-resident kernel.
 bool pairs_possible(const fs3d_sim* s) {
-    static const bool off = getenv("FSAMD_NO_SWEEP_PAIRS") && getenv("FSAMD_NO_SWEEP_PAIRS")[0] == '1';
+    const char* no = getenv("FSAMD_NO_SWEEP_PAIRS");   // read per call: tests switch it between simulations
+    const bool off = no && no[0] == '1';
     return !off && s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel == FS_SWEEP_FUSED && s->nx % 2 == 0 &&
            s->nparts_global == 1;
 }

@@ -89,3 +89,23 @@ def test_sweep_pairs_with_subnormal_huge_and_non_finite_values(fsamd, monkeypatc
             for k in range(3):
                 a, b = o.field(k), g.get_field(k)
                 assert np.array_equal(a, b, equal_nan=True), (n, k, int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum()))
+
+
+def test_pairs_at_512_cubed_equal_single_sweeps(fsamd, monkeypatch):
+    # the full size of the multi-GPU configuration: two launches per pass there (256-column tiles and a 64 x 64
+    # remainder), several z-chunks; four sweeps in pairs against four one-pass sweeps, bit for bit
+    import fluid_simulation_amd.scenes as scenes
+    n = 512
+    fields = []
+    for no_pairs in ("0", "1"):
+        monkeypatch.setenv("FSAMD_NO_SWEEP_PAIRS", no_pairs)
+        g = fsamd.FluidSim3D(n, n, n, stop_mode=fsamd.STOP_FIXED, max_iters=1, step_mode=fsamd.STEP_REFLECTION)
+        init, per_step = scenes.SCENES["vortex_ring"]
+        init(g)
+        per_step(g, 0)
+        g.advance(1.0 / 30.0)          # a field with divergence everywhere the ring has reached
+        g.sweeps(4)
+        fields.append([g.get_field(k) for k in range(3)])
+        g.close()
+    for k in range(3):
+        assert np.array_equal(fields[0][k], fields[1][k]), k

@@ -428,7 +428,7 @@ def main():
                     one["traffic"] = rec["hbm_bytes_per_launch"]
                     one["traffic_rate"] = rec["hbm_bytes_per_launch"] / sweep_s / 1e9
                     one["traffic_source"] = "profiles/sweep_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of " \
-                                                         f"{rec.get('kernel', 'the kernel')}, collected {rec.get('collected', 'in round 1')}; not measured in this run)"
+                                                         f"{rec.get('kernel', 'the kernel')}, collected {rec.get('collected', 'earlier')}; not measured in this run)"
                     rec2 = json.load(open(pmc)).get(f"{n}_pairs")
                     if rec2 and pair_s is not None:
                         two = line["roofline" if paired else "roofline_two_sweep_pass"]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Measures the table of DESIGN.md "Ordering and the 1e-4 bar": red-black against lexicographic after 100 steps.
+# Measures red-black against lexicographic sweep order after 100 steps of the vortex ring at several sizes and stopping rules.
 # Usage (on the GPU box): bash scripts/north_star_table.sh > gpurun_out/north_star_table.txt
 set -o pipefail
 run() { timeout -k 10 "$1" python -u scripts/north_star_orders.py "${@:2}" | grep --line-buffered RESULT; }

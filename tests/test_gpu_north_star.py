@@ -12,7 +12,7 @@
       8e-5 at 128^3.  The 64^3 test bounds it by 2e-4, the 128^3 test by 1e-4;
     - once the emitter is gone (its cells turned into fluid after a blow phase) the bar holds at 64^3: < 1e-4;
 * the divergence the emitter leaves behind however long the sweeps run, bounded and shrinking with the grid.
-Measured values are printed (pytest -s) and tabulated in DESIGN.md.
+Measured values are printed (pytest -s).
 """
 import numpy as np
 import pytest

@@ -26,6 +26,10 @@ while time.time() - t0 < budget:
                advect_kernel=int(rng.integers(0, 2)), stop_mode=int(rng.choice([0, 1, 2])), max_iters=int(rng.integers(1, 9)),
                check_every=int(rng.choice([1, 2, 3])), tol=float(rng.choice([5.0, 1e-1, 1e-3])),
                omega=float(rng.choice([1.0, 1.0, 1.3])), advection=int(rng.integers(0, 2)))
+    # the tile shape of the two-sweep kernel: the library's own choice or a forced one (read per call)
+    shape = str(rng.choice(["", "64", "32", "16", "64+16", "64+32"]))
+    if shape: os.environ["FSAMD_ROWS2_LANES_PER_ROW"] = shape
+    else: os.environ.pop("FSAMD_ROWS2_LANES_PER_ROW", None)
     scale = float(rng.choice([1.0, 10.0, 60.0]))
     if FAST:      # backtraces of many cells: beyond the staged planes of the tiled advection, out of the domain
         scale = float(rng.choice([150.0, 400.0, 2000.0]))

@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fsamd_loader
 fs = fsamd_loader.load()
+if os.environ.get("FSAMD_LIB"):      # an experimental build of the library
+    fs.load_library(os.environ["FSAMD_LIB"])
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
     (128, 128, 128), (192, 192, 192), (256, 256, 256), (384, 384, 384), (512, 512, 512), (256, 512, 256),
     (1024, 1024, 128), (64, 256, 256), (128, 256, 256), (640, 320, 320)]

@@ -540,7 +540,7 @@ FusedRanges fused_ranges(const Part& p) {
 inline int pick_chunks(int planes, int tiles, int slots) {
     int best_c = 1;
     double best = 1e300;
-    for (int c = 1; c <= std::max(1, planes / 8); ++c) {
+    for (int c = 1; c <= std::max(1, planes / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
         const int zc = div_up(planes, c);
         const int rounds = div_up(tiles * div_up(planes, zc), slots);
         const double cost = (double)rounds * (zc + 6);
@@ -675,7 +675,7 @@ Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu, int ntx = 0) {   // ntx: tha
     const int nzl = s->parts[0].g.nzl;
     int best_c = 1;
     t.steps = 1e300;
-    for (int c = 1; c <= std::max(1, nzl / 8); ++c) {
+    for (int c = 1; c <= std::max(1, nzl / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
         const int zc = div_up(nzl, c);
         const double cost = (double)div_up(t.ntx * t.nty * div_up(nzl, zc), per_cu * s->num_cus) * (zc + 12);
         if (cost < t.steps) { t.steps = cost; best_c = c; }
@@ -1257,8 +1257,8 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         if (with_res) {   // the launches of one advection write their partials one after the other
             const size_t blocks = (size_t)g.x * g.y * g.z;
             if (!p.adv_part) {
-                // at most planes/8 chunks per launch, three launches per advection
-                const size_t cap = (size_t)tiles * (size_t)(p.own_planes() / 8 + 6);
+                // at most planes/2 chunks per launch, three launches per advection
+                const size_t cap = (size_t)tiles * (size_t)(p.own_planes() / 2 + 6);
                 SIM_HIP(hipMalloc((void**)&p.adv_part, cap * 2 * sizeof(double)));
                 p.adv_cap = cap;
             }

@@ -26,6 +26,8 @@ The printed JSON line carries
                     formulation touches every face once per colour (50 B per cell and sweep): that figure and the
                     blocking factor stand beside it as `algorithmic_*`.  The other of the two sweep kernels is
                     reported as roofline_one_sweep_pass / roofline_two_sweep_pass;
+                    velocity_copy_us / launch_over_copy: the time of a kernel that only streams the three velocity fields
+                    from one generation to the other, measured in the same run - the floor of any pass;
   roofline_advect   the same for the two advection kernels of the step (33 and 45 B per cell);
   cpu_baseline      the CPU oracle in the reference's own execution model (one thread, lexicographic sweeps,
                     serial-order advection) on a bounded sample, and `cpu_baseline_openmp`, its red-black loops on
@@ -326,6 +328,10 @@ def main():
         npair = 10
         sim.time_sweep_pairs(2)
         pair_s = sim.time_sweep_pairs(npair) * 1e-3 / npair   # one launch = two full sweeps
+    # the yardstick of a sweep pass: the three velocity fields streamed from one generation of the arrays to the other
+    sim.time_field_copies(2)
+    ncopy = 10
+    copy_s = sim.time_field_copies(ncopy) * 1e-3 / ncopy
     adv = None
     if a.advection == "semi_lagrange":
         nadv = 6
@@ -416,6 +422,14 @@ def main():
             }
             # the dominant kernel of the step is the one most sweeps run in
             line["roofline" if paired else "roofline_two_sweep_pass"] = pair
+        # what the memory system gives a kernel that only copies the velocity (24 of the 25 bytes per cell of a pass), measured
+        # in this run: a pass cannot be faster, whatever the datasheet peak
+        copy_rate = 24.0 * esz_scale * cells_local / copy_s / 1e9
+        for key in ("roofline", "roofline_one_sweep_pass", "roofline_two_sweep_pass"):
+            if key in line:
+                line[key]["velocity_copy_us"] = copy_s * 1e6
+                line[key]["velocity_copy_rate"] = copy_rate
+                line[key]["launch_over_copy"] = line[key]["launch_us"] / (copy_s * 1e6)
         if adv:
             line["roofline_advect"] = adv
         pmc = os.path.join(ROOT, "profiles", "sweep_traffic.json")

@@ -42,7 +42,7 @@ EXPORTS = [
     "fs3d_get_config", "fs3d_last_error", "fs3d_set_field", "fs3d_get_field", "fs3d_get_field_plane",
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
-    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_sweep_pairs", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
+    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_sweep_pairs", "fs3d_time_field_copies", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
     "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fs3d_residual_noalloc",
     "fsamd_comm_unique_id", "fsamd_comm_selftest",
@@ -125,6 +125,7 @@ def load_library(path=None):
         "fs3d_sweeps": (I, [P, I]),
         "fs3d_time_sweeps": (I, [P, I, C.POINTER(D)]),
         "fs3d_time_sweep_pairs": (I, [P, I, C.POINTER(D)]),
+        "fs3d_time_field_copies": (I, [P, I, C.POINTER(D)]),
         "fs3d_time_advections": (I, [P, I, D, I, C.POINTER(D)]),
         "fs3d_project": (I, [P, C.POINTER(I), C.POINTER(D)]),
         "fs3d_residual": (I, [P, C.POINTER(D), C.POINTER(D)]),
@@ -346,6 +347,11 @@ class FluidSim3D:
     def time_sweep_pairs(self, npairs):
         ms = C.c_double()
         self._chk(self.lib.fs3d_time_sweep_pairs(self.h, npairs, C.byref(ms)))
+        return ms.value
+
+    def time_field_copies(self, n):
+        ms = C.c_double()
+        self._chk(self.lib.fs3d_time_field_copies(self.h, n, C.byref(ms)))
         return ms.value
 
     def time_advections(self, n, t_step, reflected=False):

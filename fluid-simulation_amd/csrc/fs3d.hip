@@ -2161,6 +2161,38 @@ int fs3d_time_sweep_pairs(fs3d_sim* s, int npairs, double* ms) {
     return FS_OK;
 }
 
+// The three velocity fields streamed from one generation to the other: what any pass of a sweep has to do at least.
+__global__ void __launch_bounds__(256)
+k_copy_fields(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c, uint4* __restrict__ x,
+              uint4* __restrict__ y, uint4* __restrict__ z, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        x[i] = a[i]; y[i] = b[i]; z[i] = c[i];
+    }
+}
+
+int fs3d_time_field_copies(fs3d_sim* s, int n, double* ms) {
+    SIM_GUARD(s);
+    if (n < 1) return set_err(s, FS_EINVAL, "n must be >= 1");
+    FS_TRY(prepare(s));
+    FS_TRY(join_halos(s));
+    if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);   // the other generation is about to be overwritten
+    SIM_HIP(hipEventRecord(s->ev[0], s->stream));
+    for (int i = 0; i < n; ++i)
+        for (Part& p : s->parts) {
+            const size_t n16 = p.n * s->esz / 16;   // (the tail of an array that is no multiple of 16 bytes is not part of the measurement)
+            hipLaunchKernelGGL(k_copy_fields, dim3(8192), dim3(256), 0, s->stream, (const uint4*)p.f[s->curv][0],
+                               (const uint4*)p.f[s->curv][1], (const uint4*)p.f[s->curv][2], (uint4*)p.f[s->curv ^ 1][0],
+                               (uint4*)p.f[s->curv ^ 1][1], (uint4*)p.f[s->curv ^ 1][2], n16);
+        }
+    SIM_HIP(hipGetLastError());
+    SIM_HIP(hipEventRecord(s->ev[1], s->stream));
+    SIM_HIP(hipEventSynchronize(s->ev[1]));
+    float t = 0;
+    SIM_HIP(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+    if (ms) *ms = t;
+    return FS_OK;
+}
+
 int fs3d_time_sweeps(fs3d_sim* s, int n, double* ms) {
     SIM_GUARD(s);
     FS_TRY(prepare(s));

@@ -235,6 +235,10 @@ int fs3d_time_sweeps(fs3d_sim *sim, int n, double *ms);
  * stopping rule on a single domain with FS_SWEEP_FUSED and an even nx: one launch applies two full red-black
  * sweeps in one pass over HBM, bit for bit two launches of one sweep); FS_ESTATE where that kernel does not apply. */
 int fs3d_time_sweep_pairs(fs3d_sim *sim, int npairs, double *ms);
+/* The yardstick of those two: n times the three velocity fields streamed from the current generation of the arrays
+ * to the other one (12 bytes read and 12 written per cell, what any pass of a sweep has to move at least), timed the
+ * same way.  The state is not changed.  No counterpart in the reference.                                             */
+int fs3d_time_field_copies(fs3d_sim *sim, int n, double *ms);
 /* The same for the advection: n advections of length t_step back to back (reflected == 0: semi_lagrange of
  * the current state, main.cpp:256-291; else the second half advection of the advection-reflection step,
  * which carries the reflection of a copy of the current velocity), *ms = device time between the events.   */

@@ -413,7 +413,7 @@ def main():
                 "bytes_per_cell": one_pass_bytes, "bytes_per_launch": one_pass_bytes * cells_local, "launch_us": pair_s * 1e6,
                 "sweeps_per_launch": 2, "us_per_sweep": pair_s * 1e6 / 2,
                 "basis": "bytes one launch has to move (every face and flag read once, every face written once); the launch does the "
-                         "work of two sweeps, so it is bound by the vector ALUs and its barriers rather than by HBM",
+                         "work of two sweeps; see launch_over_copy for its distance from a plain copy of the velocity",
                 "algorithmic_bytes_per_cell": 2 * algorithmic_bytes, "blocking_factor": 4,
                 "algorithmic_rate": 2 * algorithmic_bytes * cells_local / pair_s / 1e9,
                 "full_step_bytes_per_cell": bpc,

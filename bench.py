@@ -349,7 +349,11 @@ def main():
                              "bytes_per_cell": refl_b, "launch_us": refl_s * 1e6,
                              "achieved": refl_b * cells_local / refl_s / 1e9,
                              "frac": refl_b * cells_local / refl_s / 1e9 / HBM_PEAK_GBS},
-               "note": "issue-bound (vector ALU), not bandwidth-bound: the fraction says how far from the HBM roofline it sits"}
+               "note": "copy_floor_us: the measured time of a plain copy of the velocity (velocity_copy_us) scaled to the bytes "
+                       "this kernel has to move; launch_over_floor says how far above it the kernel runs"}
+        for key, nbytes in (("self", adv_b), ("reflected", refl_b)):
+            adv[key]["copy_floor_us"] = copy_s * 1e6 * nbytes / (24.0 * esz_scale)
+            adv[key]["launch_over_floor"] = adv[key]["launch_us"] / adv[key]["copy_floor_us"]
     barrier()
 
     line = None

@@ -2162,10 +2162,15 @@ int fs3d_time_sweep_pairs(fs3d_sim* s, int npairs, double* ms) {
 }
 
 // The three velocity fields streamed from one generation to the other: what any pass of a sweep has to do at least.
+// Every workgroup copies one contiguous piece of each field, and there are many more workgroups than the GPU holds
+// at once: of the plain copies tried (grid-stride or contiguous pieces, 2 048 to 32 768 workgroups, plain or
+// non-temporal accesses, one stream or three, base addresses skewed against each other) this is the fastest at 512^3.
 __global__ void __launch_bounds__(256)
 k_copy_fields(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c, uint4* __restrict__ x,
               uint4* __restrict__ y, uint4* __restrict__ z, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         x[i] = a[i]; y[i] = b[i]; z[i] = c[i];
     }
 }
@@ -2180,7 +2185,7 @@ int fs3d_time_field_copies(fs3d_sim* s, int n, double* ms) {
     for (int i = 0; i < n; ++i)
         for (Part& p : s->parts) {
             const size_t n16 = p.n * s->esz / 16;   // (the tail of an array that is no multiple of 16 bytes is not part of the measurement)
-            hipLaunchKernelGGL(k_copy_fields, dim3(8192), dim3(256), 0, s->stream, (const uint4*)p.f[s->curv][0],
+            hipLaunchKernelGGL(k_copy_fields, dim3(16384), dim3(256), 0, s->stream, (const uint4*)p.f[s->curv][0],
                                (const uint4*)p.f[s->curv][1], (const uint4*)p.f[s->curv][2], (uint4*)p.f[s->curv ^ 1][0],
                                (uint4*)p.f[s->curv ^ 1][1], (uint4*)p.f[s->curv ^ 1][2], n16);
         }

@@ -38,8 +38,10 @@ struct AdvTile {
 // cell are in registers here anyway; the kernel then also adds up the squared divergences that k_div_sumsq
 // would (same cells, same per-cell value), one partial sum per workgroup, so that the projection's stopping
 // rule can be verified without a pass of its own over the velocity.
+// (second launch bound: waves per SIMD the register budget must allow - six for the four-field variant of
+// 4-byte elements, three workgroups per CU; the seven-field variants are held to two workgroups by their LDS)
 template <typename T, typename OFF, bool SEP, bool SLAB, bool REFL = false>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, sizeof(T) == 4 ? (SEP ? 4 : 6) : 1)
 k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __restrict__ qw,
                const T* __restrict__ qd, const T* __restrict__ U, const T* __restrict__ V, const T* __restrict__ W,
                T* __restrict__ ou, T* __restrict__ ov, T* __restrict__ ow, T* __restrict__ od, T* __restrict__ cu,
@@ -110,117 +112,184 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     // The step of a safe tile and plane is compiled without them (SAFE), so that no trace of the tests is left.
     const bool safe_xy = x0 >= 2 && x0 + C::TX <= g.nx - 2 && y0 >= 2 && y0 + C::TY <= g.ny - 2;
 
-    // A sample of field f at the backtrace of (x, y, gz) along (dx, dy, dz).  The eight LDS reads are
-    // unconditional (from the own cell when the backtrace left the window) so that the reads of all samples of
-    // a cell are in flight together; a sample outside the window then takes the general path of the direct
-    // kernel: validity of every tap, clamped base address, global loads.
-    auto sample = [&](auto safe_tag, int f, T dx, T dy, T dz, int gz, int slot_m, int slot_c, int slot_p, bool& oob) -> T {
+    // ---- samples -----------------------------------------------------------------------------------------
+    // The usual sample ends inside the staged window (|v| dt < 1 cell) and has a finite result.  The step is
+    // written for that case without a branch: every sample of a cell reads its eight taps from LDS at an
+    // address clamped into the window and notes in `bad` whether it was entitled to; a cell with a bad sample
+    // (backtrace outside the window or beyond 2^23, non-finite tap or position) is then computed again, all
+    // four samples, by the general path of the direct kernel (validity of every tap, global loads).  Both
+    // paths form the same products in the same order from the same values, so the result does not depend on
+    // which one ran.
+    //
+    // What the vector ALU charges (measured, eight waves per SIMD): fp32 add/sub/mul, moves, and/or and 32-bit
+    // adds on registers or literals issue in about 1.05-1.2 ns per wave and SIMD; anything that reads a scalar
+    // register, and conversions, floor, compares, selects, min/max, shifts, three-operand integer adds and
+    // 24-bit multiplies take about 1.85 ns.  The in-window sample is therefore written on register operands,
+    // with the tap address formed from the signs of floor(p) - own coordinate (each -1 or 0 inside the window)
+    // instead of converted integer coordinates.
+    const T xf = (T)x, yf = (T)y, tv = t_step;
+    constexpr uint32_t ESZ = sizeof(T), FS = NPL * PS * ESZ;   // bytes of an element, of one field's ring
+    const uint32_t wl4 = (uint32_t)wl * ESZ;
+    // |v| dt below this bound puts floor(p) at the own coordinate or one below it, whatever the rounding of
+    // own coordinate - v dt (coordinates below 8192 for 4-byte elements; else no sample counts as inside)
+    const T lim = sizeof(T) == 4 ? (max(max(g.nx, g.ny), g.gnz) <= 8192 ? (T)0.998046875 : (T)0) : (T)0.99999904632568359375;
+    auto sign_mask = [](T v) -> uint32_t {   // all ones for a negative value, zero otherwise
+        if constexpr (sizeof(T) == 4) return (uint32_t)(__float_as_int(v) >> 31);
+        else return (uint32_t)(__double_as_longlong(v) >> 63);
+    };
+    constexpr uint32_t AMAX = (C::WY - 2) * WX + WX - 2;   // last window element whose +1, +WX, +WX+1 exist
+
+    // sB, sC = byte offsets of the ring slots of planes z, z+1; dAB, dBC = slot(z-1) - slot(z), slot(z) - slot(z+1)
+    // (uniform over the workgroup)
+    auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, int gz, uint32_t sB, uint32_t sC, uint32_t dAB,
+                          uint32_t dBC, bool& bad) -> T {
         constexpr bool SAFE = decltype(safe_tag)::value;
         const T one = (T)1, zero = (T)0;
-        const T px = (T)x - dx * t_step, py = (T)y - dy * t_step, pz = (T)gz - dz * t_step;
+        const T dxt = dx * tv, dyt = dy * tv, dzt = dz * tv;
+        const T px = xf - dxt, py = yf - dyt, pz = zf - dzt;
         const T bx = floor(px), by = floor(py), bz = floor(pz);
         const T fu = px - bx, fv = py - by, fw = pz - bz;
-        const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
-        // (a backtrace beyond 2^23, which the reference treats apart (main.cpp:391-393), converts to an integer far
-        // outside the window and takes the general path below)
-        const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(ibz - (gz - R));
-        const bool in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
         FastTrace<T, OFF> tr;
-        tr.far = false;
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
-        // tap b is read when 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3 (main.cpp:411-435)
-        if constexpr (!SAFE) {
-            const uint32_t mx = (uint32_t)(g.nx - 2), my = (uint32_t)(g.ny - 2), mz = (uint32_t)(g.gnz - 2);
-            tr.x0 = (uint32_t)ibx - 1u < mx ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < mx ? tr.x1 : zero;
-            tr.y0 = (uint32_t)iby - 1u < my ? tr.y0 : zero; tr.y1 = (uint32_t)iby < my ? tr.y1 : zero;
-            tr.z0 = (uint32_t)ibz - 1u < mz ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < mz ? tr.z1 : zero;
+        uint32_t a4, mz;   // byte offset of tap 0 inside a plane of the window; all ones if the lower tap plane is z-1
+        bool in;
+        if constexpr (SAFE) {
+            in = fmax(fmax(fabs(dxt), fabs(dyt)), fabs(dzt)) < lim;   // (false for a NaN)
+            // floor(p) - own coordinate is -1 or 0 per axis inside the window; the masks are all ones or zero whatever
+            // the value, so the address stays inside the window for every lane
+            const uint32_t mx = sign_mask(bx - xf), my = sign_mask(by - yf);
+            mz = sign_mask(bz - zf);
+            a4 = wl4 + (mx & (0u - ESZ)) + (my & (0u - (uint32_t)WX * ESZ));
+        } else {
+            // next to the shell the taps the reference does not read get a zero weight: tap b is read when
+            // 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3 (main.cpp:411-435)
+            const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
+            const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(ibz - (gz - R));
+            in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
+            const uint32_t nmx = (uint32_t)(g.nx - 2), nmy = (uint32_t)(g.ny - 2), nmz = (uint32_t)(g.gnz - 2);
+            tr.x0 = (uint32_t)ibx - 1u < nmx ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < nmx ? tr.x1 : zero;
+            tr.y0 = (uint32_t)iby - 1u < nmy ? tr.y0 : zero; tr.y1 = (uint32_t)iby < nmy ? tr.y1 : zero;
+            tr.z0 = (uint32_t)ibz - 1u < nmz ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < nmz ? tr.z1 : zero;
+            // (24-bit multiply: full rate, where a 32-bit multiply runs at a quarter of it; the factors are small)
+            uint32_t aw;   // ay * WX + ax
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aw) : "v"(ay), "s"((uint32_t)WX), "v"(ax));
+            a4 = min(aw, AMAX) * ESZ;
+            mz = az - 1u;
         }
+        // the lower plane of the taps is z-1 (mz all ones) or z: the slot offsets follow by masking the differences
+        // of the slots.  (The slot and field offsets as one scalar each: split off as a constant, the field offset
+        // would not fit the offset field of a two-element LDS read and cost an addition per tap row.)
+        uint32_t kB = sB + (uint32_t)f * FS, kC = sC + (uint32_t)f * FS;
+        asm volatile("" : "+s"(kB), "+s"(kC));
+        const uint32_t o0 = a4 + (mz & dAB) + kB;
+        const uint32_t o1 = a4 + (mz & dBC) + kC;
+        const T* p0 = reinterpret_cast<const T*>(lds_raw + o0);
+        const T* p1 = reinterpret_cast<const T*>(lds_raw + o1);
         Taps<T> t;
-        // (24-bit multiplies: full rate, where a 32-bit multiply runs at a quarter of it; the factors are small)
-        uint32_t aw;   // ay * WX + ax (written out: the compiler would pick the 64-bit multiply-add, which is no faster)
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aw) : "v"(ay), "s"((uint32_t)WX), "v"(ax));
-        const int a = in ? (int)aw : wl;
-        // the lower plane of the taps is z-1 (az == 0) or z; the ring slots of z-1, z, z+1 are the same for the
-        // whole workgroup (slot_m, slot_c, slot_p: scalars)
-        const bool low = in && az == 0;
-        const T* p0 = L + f * NPL * PS + (low ? slot_m : slot_c) + a;
-        const T* p1 = L + f * NPL * PS + (low ? slot_c : slot_p) + a;
         t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[WX]; t.s[3] = p1[0];
         t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
-        if (__builtin_expect(!in, 0)) {
-            tr = fast_prepare<T, OFF, SLAB>(g, x, y, gz, dx, dy, dz, t_step);
-            oob = oob || tr.oob;
-            // volatile: keeps these loads apart from the LDS reads above (merged, the pair becomes one
-            // generic-address load per tap, which is served at a fraction of the LDS rate)
-            const volatile T* r00 = at_byte(src[f], trace_base(g, tr));
-            const volatile T* r10 = at_byte(src[f], trace_base(g, tr) + sy);
-            const volatile T* r01 = at_byte(src[f], trace_base(g, tr) + tr.dz1);
-            const volatile T* r11 = at_byte(src[f], trace_base(g, tr) + tr.dz1 + sy);
-            t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
-            t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
-            if (REFL && f < 3) {
-                const volatile T* c00 = at_byte(src[4 + f], trace_base(g, tr));
-                const volatile T* c10 = at_byte(src[4 + f], trace_base(g, tr) + sy);
-                const volatile T* c01 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1);
-                const volatile T* c11 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1 + sy);
-                t.s[0] = (T)2 * c00[0] - t.s[0]; t.s[1] = (T)2 * c00[1] - t.s[1]; t.s[2] = (T)2 * c10[0] - t.s[2];
-                t.s[3] = (T)2 * c01[0] - t.s[3]; t.s[4] = (T)2 * c10[1] - t.s[4]; t.s[5] = (T)2 * c01[1] - t.s[5];
-                t.s[6] = (T)2 * c11[0] - t.s[6]; t.s[7] = (T)2 * c11[1] - t.s[7];
-            }
+        T r = fast_combine(tr, t);
+        asm volatile("" : "+v"(r));   // (keeps the sums of two samples from being zipped into packed additions, which costs moves and saves nothing)
+        bad = bad || !in;
+        return r;
+    };
+    // the general path: the sample of the direct kernel
+    auto slow_sample = [&](int f, T dx, T dy, T dz, int gz, bool& oob) -> T {
+        FastTrace<T, OFF> tr = fast_prepare<T, OFF, SLAB>(g, x, y, gz, dx, dy, dz, t_step);
+        oob = oob || tr.oob;
+        Taps<T> t;
+        const T* r00 = at_byte(src[f], trace_base(g, tr));
+        const T* r10 = at_byte(src[f], trace_base(g, tr) + sy);
+        const T* r01 = at_byte(src[f], trace_base(g, tr) + tr.dz1);
+        const T* r11 = at_byte(src[f], trace_base(g, tr) + tr.dz1 + sy);
+        t.s[0] = r00[0]; t.s[1] = r00[1]; t.s[2] = r10[0]; t.s[3] = r01[0];
+        t.s[4] = r10[1]; t.s[5] = r01[1]; t.s[6] = r11[0]; t.s[7] = r11[1];
+        if (REFL && f < 3) {
+            const T* c00 = at_byte(src[4 + f], trace_base(g, tr));
+            const T* c10 = at_byte(src[4 + f], trace_base(g, tr) + sy);
+            const T* c01 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1);
+            const T* c11 = at_byte(src[4 + f], trace_base(g, tr) + tr.dz1 + sy);
+            t.s[0] = (T)2 * c00[0] - t.s[0]; t.s[1] = (T)2 * c00[1] - t.s[1]; t.s[2] = (T)2 * c10[0] - t.s[2];
+            t.s[3] = (T)2 * c01[0] - t.s[3]; t.s[4] = (T)2 * c10[1] - t.s[4]; t.s[5] = (T)2 * c01[1] - t.s[5];
+            t.s[6] = (T)2 * c11[0] - t.s[6]; t.s[7] = (T)2 * c11[1] - t.s[7];
         }
         return fast_finish(tr, t);
     };
 
     double racc = 0;
-    auto compute = [&](auto safe_tag, int z, uint32_t fl) {
+    // One interior cell: the 13-point neighbourhood of the carrying velocity, the three velocity samples, the
+    // density sample.  `smp(f, dx, dy, dz)` is the sampler; `first` says that this is the cell's first pass.
+    auto cell = [&](auto&& smp, int z, uint32_t fl, bool first, T& nu, T& nv, T& nw, T& nd) -> T {
+        const T four = (T)4, two = (T)2;
+        const bool fluid = fl & FL_SELF_FLUID;
+        const T* Uc = plane(VF + 0, z) + wl; const T* Uzm = plane(VF + 0, z - 1) + wl;
+        const T* Vc = plane(VF + 1, z) + wl; const T* Vzm = plane(VF + 1, z - 1) + wl;
+        const T* Wc = plane(VF + 2, z) + wl; const T* Wzp = plane(VF + 2, z + 1) + wl;
+        const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uc[-WX], u_xp_ym = Uc[1 - WX], u_zm = Uzm[0], u_xp_zm = Uzm[1];
+        const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vc[WX], v_xm_yp = Vc[WX - 1], v_zm = Vzm[0], v_yp_zm = Vzm[WX];
+        const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wc[-WX], w_ym_zp = Wzp[-WX];
+        if (first && res_part) {   // the cells and the value of k_div_sumsq
+            const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
+            if (relaxes(fl) && movable) {
+                const double dv = (double)((u_xp - u_c) + (v_yp - v_c) + (w_zp - w_c));
+                racc += dv * dv;
+            }
+        }
+        // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
+        const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
+        const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
+        const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
+        const T su = smp(0, u_c, uy, uz), sv = smp(1, vx, v_c, vz), sw = smp(2, wx, wy, w_c);
+        if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
+        // main.cpp:284-289
+        T uc, vc, wc;
+        if (density_mode == 1) {
+            uc = (nu + u_xp) / two; vc = (nv + v_yp) / two; wc = (nw + w_zp) / two;
+        } else {
+            uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
+        }
+        const T sd = smp(3, uc, vc, wc);
+        if (!(fl & FL_SELF_OBJECT)) nd = sd;
+        return (su + sv) + (sw + sd);   // non-finite if a sample is (the caller's test for the general path)
+    };
+
+    auto compute = [&](auto safe_tag, int z, uint32_t fl, T (&res)[4]) {
         const int gz = z + g.gz0;
-        const OFF e = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
-        const OFF i = e * (OFF)sizeof(T);
-        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
+        const T qu0 = plane(0, z)[wl], qv0 = plane(1, z)[wl], qw0 = plane(2, z)[wl], qd0 = plane(3, z)[wl];
+        T nu = qu0, nv = qv0, nw = qw0, nd = qd0;
         const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
         if (interior) {
-            const T four = (T)4, two = (T)2;
-            const bool fluid = fl & FL_SELF_FLUID;
-            const T* Uc = plane(VF + 0, z) + wl; const T* Uzm = plane(VF + 0, z - 1) + wl;
-            const T* Vc = plane(VF + 1, z) + wl; const T* Vzm = plane(VF + 1, z - 1) + wl;
-            const T* Wc = plane(VF + 2, z) + wl; const T* Wzp = plane(VF + 2, z + 1) + wl;
-            const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uc[-WX], u_xp_ym = Uc[1 - WX], u_zm = Uzm[0], u_xp_zm = Uzm[1];
-            const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vc[WX], v_xm_yp = Vc[WX - 1], v_zm = Vzm[0], v_yp_zm = Vzm[WX];
-            const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wc[-WX], w_ym_zp = Wzp[-WX];
-            if (res_part) {   // the cells and the value of k_div_sumsq
-                const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
-                if (relaxes(fl) && movable) {
-                    const double dv = (double)((u_xp - u_c) + (v_yp - v_c) + (w_zp - w_c));
-                    racc += dv * dv;
+            const T zf = (T)gz;
+            const uint32_t sA = (uint32_t)((z - 1) & (NPL - 1)) * PS * ESZ, sB = (uint32_t)(z & (NPL - 1)) * PS * ESZ,
+                           sC = (uint32_t)((z + 1) & (NPL - 1)) * PS * ESZ;
+            const uint32_t dAB = sA - sB, dBC = sB - sC;
+            bool bad = false;
+            const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, gz, sB, sC, dAB, dBC, bad); },
+                               z, fl, true, nu, nv, nw, nd);
+            bad = bad || !isfinite(chk);
+            if (__builtin_expect(bad, 0)) {
+                asm volatile("" ::: "memory");   // (the neighbourhood is read again rather than kept in registers for this rare case)
+                nu = qu0; nv = qv0; nw = qw0; nd = qd0;
+                bool oob_v = false, oob_d = false;
+                cell([&](int f, T dx, T dy, T dz) { return slow_sample(f, dx, dy, dz, gz, f == 3 ? oob_d : oob_v); },
+                     z, fl, false, nu, nv, nw, nd);
+                if (SLAB) {
+                    const bool oob = ((fl & FL_SELF_FLUID) && oob_v) || (!(fl & FL_SELF_OBJECT) && oob_d);
+                    if (oob) *oob_flag = 1;
                 }
             }
-            // face-collocated velocities: main.cpp:261-265, :269-273, :276-280
-            const T uy = (v_c + v_xm + v_yp + v_xm_yp) / four, uz = (w_c + w_xm + w_zp + w_xm_zp) / four;
-            const T vx = (u_c + u_ym + u_xp + u_xp_ym) / four, vz = (w_c + w_ym + w_zp + w_ym_zp) / four;
-            const T wx = (u_c + u_zm + u_xp + u_xp_zm) / four, wy = (v_c + v_zm + v_yp + v_yp_zm) / four;
-            bool oob_v = false, oob_d = false;
-            const int slot_m = ((z - 1) & (NPL - 1)) * PS, slot_c = (z & (NPL - 1)) * PS, slot_p = ((z + 1) & (NPL - 1)) * PS;
-            const T su = sample(safe_tag, 0, u_c, uy, uz, gz, slot_m, slot_c, slot_p, oob_v),
-                    sv = sample(safe_tag, 1, vx, v_c, vz, gz, slot_m, slot_c, slot_p, oob_v),
-                    sw = sample(safe_tag, 2, wx, wy, w_c, gz, slot_m, slot_c, slot_p, oob_v);
-            if (fluid) { nu = su; nv = sv; nw = sw; }   // main.cpp:260
-            // main.cpp:284-289
-            T uc, vc, wc;
-            if (density_mode == 1) {
-                uc = (nu + u_xp) / two; vc = (nv + v_yp) / two; wc = (nw + w_zp) / two;
-            } else {
-                uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
-            }
-            const T sd = sample(safe_tag, 3, uc, vc, wc, gz, slot_m, slot_c, slot_p, oob_d);
-            bool oob = fluid && oob_v;
-            if (!(fl & FL_SELF_OBJECT)) { nd = sd; oob = oob || oob_d; }
-            if (SLAB && oob) *oob_flag = 1;
         }
-        *const_cast<T*>(at_byte<T, OFF>(ou, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(ov, i)) = nv;
-        *const_cast<T*>(at_byte<T, OFF>(ow, i)) = nw; *const_cast<T*>(at_byte<T, OFF>(od, i)) = nd;
+        res[0] = nu; res[1] = nv; res[2] = nw; res[3] = nd;
+    };
+    // the results of a plane leave after the next plane but one has been committed to LDS: a wait for the staged
+    // loads then does not wait for these stores as well (loads and stores share one counter)
+    auto store = [&](int z, const T (&res)[4]) {
+        const OFF i = (((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x) * (OFF)sizeof(T);
+        *const_cast<T*>(at_byte<T, OFF>(ou, i)) = res[0]; *const_cast<T*>(at_byte<T, OFF>(ov, i)) = res[1];
+        *const_cast<T*>(at_byte<T, OFF>(ow, i)) = res[2]; *const_cast<T*>(at_byte<T, OFF>(od, i)) = res[3];
         if (cu) {
-            *const_cast<T*>(at_byte<T, OFF>(cu, i)) = nu; *const_cast<T*>(at_byte<T, OFF>(cv, i)) = nv;
-            *const_cast<T*>(at_byte<T, OFF>(cw, i)) = nw;
+            *const_cast<T*>(at_byte<T, OFF>(cu, i)) = res[0]; *const_cast<T*>(at_byte<T, OFF>(cv, i)) = res[1];
+            *const_cast<T*>(at_byte<T, OFF>(cw, i)) = res[2];
         }
     };
 
@@ -233,11 +302,14 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         if (mine) fl = flags[((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x];
         fetch(z + R + 1);
         const int gz = z + g.gz0;
+        T res[4];
         if (mine) {
-            if (safe_xy && gz >= 2 && gz <= g.gnz - 3) compute(std::true_type{}, z, fl);
-            else compute(std::false_type{}, z, fl);
+            if (safe_xy && gz >= 2 && gz <= g.gnz - 3) compute(std::true_type{}, z, fl, res);
+            else compute(std::false_type{}, z, fl, res);
         }
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
+        asm volatile("" ::: "memory");
+        if (mine) store(z, res);
         __syncthreads();
     }
     if (res_part) {   // one partial per workgroup, added in a fixed order

@@ -1,0 +1,111 @@
+// Which streaming shape the memory system serves best at 512^3 (fields far larger than the 256 MiB Infinity Cache):
+// one stream or three, base addresses of the fields offset against each other or not, plain or non-temporal
+// accesses, grid-stride or one contiguous chunk per workgroup.
+// Build: hipcc --offload-arch=gfx950 -O3 copy_variants.hip -o copy_variants
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#pragma clang diagnostic ignored "-Wunused-result"
+#pragma clang diagnostic ignored "-Wunused-value"
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int NT_LD, int NT_ST>
+__global__ void k_copy3(const f4* a, const f4* b, const f4* c, f4* x, f4* y, f4* z, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f4 p, q, r;
+        if (NT_LD) { p = __builtin_nontemporal_load(a + i); q = __builtin_nontemporal_load(b + i); r = __builtin_nontemporal_load(c + i); }
+        else { p = a[i]; q = b[i]; r = c[i]; }
+        if (NT_ST) { __builtin_nontemporal_store(p, x + i); __builtin_nontemporal_store(q, y + i); __builtin_nontemporal_store(r, z + i); }
+        else { x[i] = p; y[i] = q; z[i] = r; }
+    }
+}
+// every workgroup owns one contiguous chunk of each field
+template <int NT_ST>
+__global__ void k_copy3_chunk(const f4* a, const f4* b, const f4* c, f4* x, f4* y, f4* z, size_t n4) {
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const f4 p = a[i], q = b[i], r = c[i];
+        if (NT_ST) { __builtin_nontemporal_store(p, x + i); __builtin_nontemporal_store(q, y + i); __builtin_nontemporal_store(r, z + i); }
+        else { x[i] = p; y[i] = q; z[i] = r; }
+    }
+}
+template <int NT_ST>
+__global__ void k_copy1(const f4* a, f4* x, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f4 p = a[i];
+        if (NT_ST) __builtin_nontemporal_store(p, x + i); else x[i] = p;
+    }
+}
+template <int NT_ST>
+__global__ void k_write3(f4* x, f4* y, f4* z, size_t n4) {
+    const f4 v = {1, 2, 3, 4};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        if (NT_ST) { __builtin_nontemporal_store(v, x + i); __builtin_nontemporal_store(v, y + i); __builtin_nontemporal_store(v, z + i); }
+        else { x[i] = v; y[i] = v; z[i] = v; }
+    }
+}
+template <int NT_ST>
+__global__ void k_write1(f4* x, size_t n4) {
+    const f4 v = {1, 2, 3, 4};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        if (NT_ST) __builtin_nontemporal_store(v, x + i); else x[i] = v;
+    }
+}
+
+int main(int argc, char** argv) {
+    const int n = 512;
+    const size_t cells = (size_t)n * n * n, bytes = cells * 4, n4 = cells / 4;
+    // one arena, fields carved out of it at chosen offsets
+    const size_t slack = 64u << 20;
+    char* arena; hipMalloc(&arena, 6 * (bytes + slack)); hipMemset(arena, 0, 6 * (bytes + slack));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](auto launch, const char* name, double bytes_moved) {
+        launch(); launch();
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-64s %8.1f us  %6.2f TB/s\n", name, ms / 10 * 1e3, bytes_moved / (ms / 10 * 1e-3) / 1e12);
+        fflush(stdout);
+    };
+    const size_t skews[] = {0, 256, 4096, 4096 + 256, 65536 + 4096 + 256, (1u << 20) + 65536 + 4096 + 256, 3 * 4096 + 3 * 256};
+    for (size_t skew : skews) {
+        f4* f[6];
+        for (int k = 0; k < 6; ++k) f[k] = (f4*)(arena + k * (bytes + slack) + k * skew);
+        char name[128];
+        for (int blocks : {2048, 8192}) {
+            snprintf(name, sizeof name, "skew %8zu  %5d wg  copy3 plain", skew, blocks);
+            timeit([&] { hipLaunchKernelGGL((k_copy3<0, 0>), dim3(blocks), dim3(256), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n4); }, name, 6.0 * bytes);
+        }
+        snprintf(name, sizeof name, "skew %8zu   2048 wg  copy3 nt stores", skew);
+        timeit([&] { hipLaunchKernelGGL((k_copy3<0, 1>), dim3(2048), dim3(256), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n4); }, name, 6.0 * bytes);
+        snprintf(name, sizeof name, "skew %8zu   2048 wg  copy3 nt loads+stores", skew);
+        timeit([&] { hipLaunchKernelGGL((k_copy3<1, 1>), dim3(2048), dim3(256), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n4); }, name, 6.0 * bytes);
+        snprintf(name, sizeof name, "skew %8zu   2048 wg  copy3 chunk per workgroup", skew);
+        timeit([&] { hipLaunchKernelGGL((k_copy3_chunk<0>), dim3(2048), dim3(256), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n4); }, name, 6.0 * bytes);
+        snprintf(name, sizeof name, "skew %8zu  16384 wg  copy3 chunk per workgroup", skew);
+        timeit([&] { hipLaunchKernelGGL((k_copy3_chunk<0>), dim3(16384), dim3(256), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n4); }, name, 6.0 * bytes);
+        snprintf(name, sizeof name, "skew %8zu   2048 wg  write3 plain", skew);
+        timeit([&] { hipLaunchKernelGGL((k_write3<0>), dim3(2048), dim3(256), 0, 0, f[3], f[4], f[5], n4); }, name, 3.0 * bytes);
+        snprintf(name, sizeof name, "skew %8zu   2048 wg  write3 nt", skew);
+        timeit([&] { hipLaunchKernelGGL((k_write3<1>), dim3(2048), dim3(256), 0, 0, f[3], f[4], f[5], n4); }, name, 3.0 * bytes);
+    }
+    // one long stream: 3 fields' worth of bytes as a single array
+    {
+        f4* a = (f4*)arena; f4* x = (f4*)(arena + 3 * (bytes + slack));
+        for (int blocks : {2048, 8192, 32768})  {
+            char name[128];
+            snprintf(name, sizeof name, "one stream of 3 fields  %5d wg  copy1 plain", blocks);
+            timeit([&] { hipLaunchKernelGGL((k_copy1<0>), dim3(blocks), dim3(256), 0, 0, a, x, 3 * n4); }, name, 6.0 * bytes);
+            snprintf(name, sizeof name, "one stream of 3 fields  %5d wg  copy1 nt stores", blocks);
+            timeit([&] { hipLaunchKernelGGL((k_copy1<1>), dim3(blocks), dim3(256), 0, 0, a, x, 3 * n4); }, name, 6.0 * bytes);
+            snprintf(name, sizeof name, "one stream of 3 fields  %5d wg  write1 plain", blocks);
+            timeit([&] { hipLaunchKernelGGL((k_write1<0>), dim3(blocks), dim3(256), 0, 0, x, 3 * n4); }, name, 3.0 * bytes);
+            snprintf(name, sizeof name, "one stream of 3 fields  %5d wg  write1 nt", blocks);
+            timeit([&] { hipLaunchKernelGGL((k_write1<1>), dim3(blocks), dim3(256), 0, 0, x, 3 * n4); }, name, 3.0 * bytes);
+        }
+    }
+    hipFree(arena);
+    return 0;
+}

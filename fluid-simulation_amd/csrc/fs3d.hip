@@ -688,12 +688,19 @@ Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu, int ntx = 0) {   // ntx: tha
 template <typename T, int NSEG, int CP, int LPR>
 int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov, int xbase = 0, int xedges = 3) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
-    auto kern = k_rb_rows2<T, NSEG, CP, LPR>;
-    SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
+    const void* kern = rows2_kernel<T, NSEG, CP, LPR>();   // (instantiated in fs_rows2.hip)
+    SIM_HIP(allow_lds(s, kern, C::lds_bytes()));
     Part& p = s->parts[0];
     dim3 b(64, t.waves, 1), g(t.ntx * t.nty * t.zgroups, 1, 1);
-    hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<T>(p, cv, 0), F<T>(p, cv, 1), F<T>(p, cv, 2), F<T>(p, ov, 0),
-                       F<T>(p, ov, 1), F<T>(p, ov, 2), p.vflags, (T)s->cfg.omega, p.zb, p.ze, t.zchunk, t.ntx, t.nty, t.rows, xbase, xedges);
+    // the arguments of k_rb_rows2, in its order and types
+    Grid grid = p.g;
+    const T *ui = F<T>(p, cv, 0), *vi = F<T>(p, cv, 1), *wi = F<T>(p, cv, 2);
+    T *uo = F<T>(p, ov, 0), *vo = F<T>(p, ov, 1), *wo = F<T>(p, ov, 2);
+    const uint8_t* vflags = p.vflags;
+    T omega = (T)s->cfg.omega;
+    int zb = p.zb, ze = p.ze, zchunk = t.zchunk, ntx = t.ntx, nty = t.nty, rows = t.rows;
+    void* args[] = {&grid, &ui, &vi, &wi, &uo, &vo, &wo, &vflags, &omega, &zb, &ze, &zchunk, &ntx, &nty, &rows, &xbase, &xedges};
+    SIM_HIP(hipLaunchKernel(kern, g, b, args, C::lds_bytes(), s->stream));
     return FS_OK;
 }
 

@@ -21,6 +21,9 @@
 
 namespace fsamd {
 
+template <bool SX, bool SY, bool SZ>
+struct AdvSafe { static constexpr bool x = SX, y = SY, z = SZ; };
+
 template <typename T, bool SEP>
 struct AdvTile {
     static constexpr int TX = 64, TY = 8, R = 1, NPL = 4;   // NPL = 2R+2 planes, a power of two
@@ -106,11 +109,11 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     const int wl = (ty + R) * WX + tx + R;   // own cell inside the window
     constexpr int VF = SEP ? 4 : 0;          // first field of the carrying velocity
 
-    // Tiles and planes at least two cells away from the shell: every tap of a backtrace that ends inside the
-    // staged window is then one the reference reads, and the per-axis validity tests (and the zeroing of
-    // weights) are skipped.  All three are uniform over the workgroup.
-    // The step of a safe tile and plane is compiled without them (SAFE), so that no trace of the tests is left.
-    const bool safe_xy = x0 >= 2 && x0 + C::TX <= g.nx - 2 && y0 >= 2 && y0 + C::TY <= g.ny - 2;
+    // Tiles and planes at least two cells away from the shell along an axis: every tap of a backtrace that ends inside
+    // the staged window is then one the reference reads, and the zeroing of weights is skipped for that axis.  All
+    // three are uniform over the workgroup; the step is compiled per combination (AdvSafe), so that a safe axis
+    // leaves no trace of the tests.
+    const bool safe_x = x0 >= 2 && x0 + C::TX <= g.nx - 2, safe_y = y0 >= 2 && y0 + C::TY <= g.ny - 2;
 
     // ---- samples -----------------------------------------------------------------------------------------
     // The usual sample ends inside the staged window (|v| dt < 1 cell) and has a finite result.  The step is
@@ -137,45 +140,38 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         if constexpr (sizeof(T) == 4) return (uint32_t)(__float_as_int(v) >> 31);
         else return (uint32_t)(__double_as_longlong(v) >> 63);
     };
-    constexpr uint32_t AMAX = (C::WY - 2) * WX + WX - 2;   // last window element whose +1, +WX, +WX+1 exist
+    // Next to the shell some taps are ones the reference does not read: tap b is read when 1 <= b <= n-2, tap b+1 when
+    // 0 <= b <= n-3 (main.cpp:411-435).  Inside the window that is the low tap of a cell at coordinate 1 whose
+    // backtrace ends below it, and the high tap of a cell at n-2 whose backtrace does not; such a tap gets a zero
+    // weight.  `edge` holds the four tests of x and y as bits; a step is compiled for the axes that need them
+    // (Safe<SX, SY, SZ>: the axis is at least two cells away from the shell for the whole tile, or plane).
+    const uint32_t edge = (x == 1 ? 1u : 0u) | (x == g.nx - 2 ? 2u : 0u) | (y == 1 ? 4u : 0u) | (y == g.ny - 2 ? 8u : 0u);
+    auto bit_mask = [](uint32_t v, int b) -> uint32_t { return (uint32_t)((int32_t)(v << (31 - b)) >> 31); };
+    auto keep_unless = [](T w, uint32_t kill) -> T {   // w, or +0 where kill is all ones
+        if constexpr (sizeof(T) == 4) return __uint_as_float(__float_as_uint(w) & ~kill);
+        else return __longlong_as_double(__double_as_longlong(w) & ~(long long)(int32_t)kill);
+    };
 
     // sB, sC = byte offsets of the ring slots of planes z, z+1; dAB, dBC = slot(z-1) - slot(z), slot(z) - slot(z+1)
-    // (uniform over the workgroup)
-    auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, int gz, uint32_t sB, uint32_t sC, uint32_t dAB,
+    // (uniform over the workgroup); zedge: bit 0 = the plane is gz == 1, bit 1 = it is gz == gnz-2
+    auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, uint32_t zedge, uint32_t sB, uint32_t sC, uint32_t dAB,
                           uint32_t dBC, bool& bad) -> T {
-        constexpr bool SAFE = decltype(safe_tag)::value;
-        const T one = (T)1, zero = (T)0;
+        using S = decltype(safe_tag);
+        const T one = (T)1;
         const T dxt = dx * tv, dyt = dy * tv, dzt = dz * tv;
         const T px = xf - dxt, py = yf - dyt, pz = zf - dzt;
         const T bx = floor(px), by = floor(py), bz = floor(pz);
         const T fu = px - bx, fv = py - by, fw = pz - bz;
         FastTrace<T, OFF> tr;
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
-        uint32_t a4, mz;   // byte offset of tap 0 inside a plane of the window; all ones if the lower tap plane is z-1
-        bool in;
-        if constexpr (SAFE) {
-            in = fmax(fmax(fabs(dxt), fabs(dyt)), fabs(dzt)) < lim;   // (false for a NaN)
-            // floor(p) - own coordinate is -1 or 0 per axis inside the window; the masks are all ones or zero whatever
-            // the value, so the address stays inside the window for every lane
-            const uint32_t mx = sign_mask(bx - xf), my = sign_mask(by - yf);
-            mz = sign_mask(bz - zf);
-            a4 = wl4 + (mx & (0u - ESZ)) + (my & (0u - (uint32_t)WX * ESZ));
-        } else {
-            // next to the shell the taps the reference does not read get a zero weight: tap b is read when
-            // 1 <= b <= n-2, tap b+1 when 0 <= b <= n-3 (main.cpp:411-435)
-            const int ibx = (int)bx, iby = (int)by, ibz = (int)bz;
-            const uint32_t ax = (uint32_t)(ibx - (x0 - R)), ay = (uint32_t)(iby - (y0 - R)), az = (uint32_t)(ibz - (gz - R));
-            in = ax < (uint32_t)(WX - 1) && ay < (uint32_t)(C::WY - 1) && az < (uint32_t)(2 * R);
-            const uint32_t nmx = (uint32_t)(g.nx - 2), nmy = (uint32_t)(g.ny - 2), nmz = (uint32_t)(g.gnz - 2);
-            tr.x0 = (uint32_t)ibx - 1u < nmx ? tr.x0 : zero; tr.x1 = (uint32_t)ibx < nmx ? tr.x1 : zero;
-            tr.y0 = (uint32_t)iby - 1u < nmy ? tr.y0 : zero; tr.y1 = (uint32_t)iby < nmy ? tr.y1 : zero;
-            tr.z0 = (uint32_t)ibz - 1u < nmz ? tr.z0 : zero; tr.z1 = (uint32_t)ibz < nmz ? tr.z1 : zero;
-            // (24-bit multiply: full rate, where a 32-bit multiply runs at a quarter of it; the factors are small)
-            uint32_t aw;   // ay * WX + ax
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aw) : "v"(ay), "s"((uint32_t)WX), "v"(ax));
-            a4 = min(aw, AMAX) * ESZ;
-            mz = az - 1u;
-        }
+        const bool in = fmax(fmax(fabs(dxt), fabs(dyt)), fabs(dzt)) < lim;   // (false for a NaN)
+        // floor(p) - own coordinate is -1 or 0 per axis inside the window; the masks are all ones or zero whatever
+        // the value, so the address stays inside the window for every lane
+        const uint32_t mx = sign_mask(bx - xf), my = sign_mask(by - yf), mz = sign_mask(bz - zf);
+        if constexpr (!S::x) { tr.x0 = keep_unless(tr.x0, bit_mask(edge, 0) & mx); tr.x1 = keep_unless(tr.x1, bit_mask(edge, 1) & ~mx); }
+        if constexpr (!S::y) { tr.y0 = keep_unless(tr.y0, bit_mask(edge, 2) & my); tr.y1 = keep_unless(tr.y1, bit_mask(edge, 3) & ~my); }
+        if constexpr (!S::z) { tr.z0 = keep_unless(tr.z0, (0u - (zedge & 1u)) & mz); tr.z1 = keep_unless(tr.z1, (0u - (zedge >> 1)) & ~mz); }
+        const uint32_t a4 = wl4 + (mx & (0u - ESZ)) + (my & (0u - (uint32_t)WX * ESZ));
         // the lower plane of the taps is z-1 (mz all ones) or z: the slot offsets follow by masking the differences
         // of the slots.  (The slot and field offsets as one scalar each: split off as a constant, the field offset
         // would not fit the offset field of a two-element LDS read and cost an addition per tap row.)
@@ -253,31 +249,34 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         return (su + sv) + (sw + sd);   // non-finite if a sample is (the caller's test for the general path)
     };
 
-    auto compute = [&](auto safe_tag, int z, uint32_t fl, T (&res)[4]) {
+    // One location of plane z by the in-window path; true if the cell has to be computed again by the general path.
+    auto compute = [&](auto safe_tag, int z, uint32_t fl, T (&res)[4]) -> bool {
         const int gz = z + g.gz0;
-        const T qu0 = plane(0, z)[wl], qv0 = plane(1, z)[wl], qw0 = plane(2, z)[wl], qd0 = plane(3, z)[wl];
-        T nu = qu0, nv = qv0, nw = qw0, nd = qd0;
+        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
         const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
+        bool bad = false;
         if (interior) {
             const T zf = (T)gz;
             const uint32_t sA = (uint32_t)((z - 1) & (NPL - 1)) * PS * ESZ, sB = (uint32_t)(z & (NPL - 1)) * PS * ESZ,
                            sC = (uint32_t)((z + 1) & (NPL - 1)) * PS * ESZ;
             const uint32_t dAB = sA - sB, dBC = sB - sC;
-            bool bad = false;
-            const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, gz, sB, sC, dAB, dBC, bad); },
+            const uint32_t zedge = (gz == 1 ? 1u : 0u) | (gz == g.gnz - 2 ? 2u : 0u);
+            const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, zedge, sB, sC, dAB, dBC, bad); },
                                z, fl, true, nu, nv, nw, nd);
             bad = bad || !isfinite(chk);
-            if (__builtin_expect(bad, 0)) {
-                asm volatile("" ::: "memory");   // (the neighbourhood is read again rather than kept in registers for this rare case)
-                nu = qu0; nv = qv0; nw = qw0; nd = qd0;
-                bool oob_v = false, oob_d = false;
-                cell([&](int f, T dx, T dy, T dz) { return slow_sample(f, dx, dy, dz, gz, f == 3 ? oob_d : oob_v); },
-                     z, fl, false, nu, nv, nw, nd);
-                if (SLAB) {
-                    const bool oob = ((fl & FL_SELF_FLUID) && oob_v) || (!(fl & FL_SELF_OBJECT) && oob_d);
-                    if (oob) *oob_flag = 1;
-                }
-            }
+        }
+        res[0] = nu; res[1] = nv; res[2] = nw; res[3] = nd;
+        return bad;
+    };
+    // The same location by the general path (rare: the neighbourhood is read again rather than kept in registers).
+    auto compute_general = [&](int z, uint32_t fl, T (&res)[4]) {
+        const int gz = z + g.gz0;
+        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
+        bool oob_v = false, oob_d = false;
+        cell([&](int f, T dx, T dy, T dz) { return slow_sample(f, dx, dy, dz, gz, f == 3 ? oob_d : oob_v); }, z, fl, false, nu, nv, nw, nd);
+        if (SLAB) {
+            const bool oob = ((fl & FL_SELF_FLUID) && oob_v) || (!(fl & FL_SELF_OBJECT) && oob_d);
+            if (oob) *oob_flag = 1;
         }
         res[0] = nu; res[1] = nv; res[2] = nw; res[3] = nd;
     };
@@ -304,8 +303,14 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         const int gz = z + g.gz0;
         T res[4];
         if (mine) {
-            if (safe_xy && gz >= 2 && gz <= g.gnz - 3) compute(std::true_type{}, z, fl, res);
-            else compute(std::false_type{}, z, fl, res);
+            const bool safe_z = gz >= 2 && gz <= g.gnz - 3;
+            bool bad;
+            if (safe_x && safe_y && safe_z) bad = compute(AdvSafe<true, true, true>{}, z, fl, res);
+            else if (safe_y && safe_z) bad = compute(AdvSafe<false, true, true>{}, z, fl, res);
+            else if (safe_x && safe_z) bad = compute(AdvSafe<true, false, true>{}, z, fl, res);
+            else if (safe_x && safe_y) bad = compute(AdvSafe<true, true, false>{}, z, fl, res);
+            else bad = compute(AdvSafe<false, false, false>{}, z, fl, res);
+            if (__builtin_expect(bad, 0)) compute_general(z, fl, res);
         }
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
         asm volatile("" ::: "memory");

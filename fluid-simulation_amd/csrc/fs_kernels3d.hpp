@@ -48,7 +48,8 @@ __device__ __forceinline__ int64_t gidx(const Grid& g, int x, int y, int z) {
 // is not Fluid itself).
 __device__ __forceinline__ int visit_divisor(uint32_t vb) { return __popc(vb & FL_NBR) + (int)(vb >> 6); }
 
-__global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t* __restrict__ flags,
+// (the kernels that are no templates are static: this header is part of more than one translation unit)
+static __global__ void k_build_flags(Grid g, const uint8_t* __restrict__ cells, uint8_t* __restrict__ flags,
                               uint8_t* __restrict__ vflags) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -427,7 +428,7 @@ k_div_sumsq(Grid g, const T* __restrict__ u, const T* __restrict__ v, const T* _
 }
 
 // out[0] = sum of part[2b], out[1] = max of part[2b+1], b ascending.
-__global__ void __launch_bounds__(256) k_reduce_final(const double* __restrict__ part, int nblocks,
+static __global__ void __launch_bounds__(256) k_reduce_final(const double* __restrict__ part, int nblocks,
                                                       double* __restrict__ out) {
     double s = 0, m = 0;
     // fixed order: thread t adds blocks t, t+256, ...; then the fixed tree of block_sum_max
@@ -845,7 +846,7 @@ __global__ void k_scatter(int n, const int64_t* __restrict__ idx, const float* _
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) field[idx[k]] = (T)(scale * val[k]);
 }
-__global__ void k_scatter_cells(int n, const int64_t* __restrict__ idx, uint8_t type, uint8_t* __restrict__ cells) {
+static __global__ void k_scatter_cells(int n, const int64_t* __restrict__ idx, uint8_t type, uint8_t* __restrict__ cells) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) cells[idx[k]] = type;
 }

@@ -56,10 +56,20 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     T* L = reinterpret_cast<T*>(lds_raw);   // [field][ring slot][WY][WX]
 
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * C::TX + tx;
-    const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  They are renumbered so that an XCD
+    // works on a run of consecutive tiles - whole rows of x-tiles, neighbouring rows, of one z-chunk: a staged row
+    // is 66 elements that start one element before a 256-byte boundary, so its first and last 128-byte line are
+    // lines the x-neighbour needs in full, and with the neighbour on the same XCD they come out of that L2 instead
+    // of crossing the fabric a second time (the apron rows of the y-neighbours likewise).  Placement is a speed
+    // matter only; the tile a workgroup works on decides everything else.
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total = gridDim.x * gridDim.y * gridDim.z;
+    const int xcd = lin & 7, qq = total >> 3, rem = total & 7;
+    const int tile = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (lin >> 3);
+    const int bx = tile % gridDim.x, by = (tile / gridDim.x) % gridDim.y, bz = tile / (gridDim.x * gridDim.y);
+    const int x0 = bx * C::TX, y0 = by * C::TY;
     // a workgroup's planes: zlen of them every zchunk planes (zlen = zchunk, except where one launch serves the
     // planes next to a slab's lower and upper interface)
-    const int c0 = zb + blockIdx.z * zchunk, c1 = min(c0 + zlen, ze);
+    const int c0 = zb + bz * zchunk, c1 = min(c0 + zlen, ze);
     const OFF sy = (OFF)g.nx * (OFF)sizeof(T), sz = (OFF)g.nx * (OFF)g.ny * (OFF)sizeof(T);
     const T* src[7] = {qu, qv, qw, qd, U, V, W};
 
@@ -326,7 +336,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             double t = 0;
 #pragma unroll
             for (int k = 0; k < C::NT / 64; ++k) t += red[k];
-            const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int bid = tile;   // (the partials are added in the order of the tiles, wherever they ran)
             res_part[2 * bid] = t;
             res_part[2 * bid + 1] = 0;
         }

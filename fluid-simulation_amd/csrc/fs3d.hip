@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <set>
@@ -94,7 +95,8 @@ struct fs3d_sim {
     bool cells_dirty = true;
     int halo_dirty = 7;          // halo planes that lag their owners: bit 0 velocity, bit 1 density, bit 2 scratch velocity
     double* dres = nullptr;      // 2 doubles per local part, then the combined record: sum, out-of-halo count, max
-    double* hres = nullptr;      // pinned mirror of the combined record
+    double* hres = nullptr;      // pinned mirror of the combined record; [3] = ticket of the record (single-part handles)
+    double ticket = 0.0;         // ticket of the record queued last
     int* doob = nullptr;         // device flag the advection kernels raise: a backtrace left the slab's halo
     ncclComm_t comm = nullptr;
     ncclComm_t comm_red = nullptr;   // the communicator of the scalar all-reduces: a copy of `comm` where the library
@@ -834,6 +836,67 @@ int queue_reduction(fs3d_sim* s, bool want_max) {
     return FS_OK;
 }
 
+// One part on one rank (the usual single-GPU case): the partials of a reduction kernel are added up, combined and
+// written into the pinned host record by ONE kernel - in the order and with the operations of k_reduce_final followed
+// by k_combine_parts - instead of two kernels and a copy, and the host does not wait for the stream to drain: the
+// kernel writes a ticket behind the values (host[3], after a system-scope fence) and the host polls the pinned word.
+// A stream synchronisation sleeps and wakes on an interrupt, which leaves the GPU idle for about 30 us per
+// evaluation of the stopping rule (a tenth of the 256^3 step); the poll sees the ticket within a few microseconds.
+__global__ void __launch_bounds__(256) k_reduce_to_host(const double* __restrict__ part, int nblocks, const int* __restrict__ oob,
+                                                        double* __restrict__ dres, volatile double* __restrict__ host, double ticket) {
+    double sm = 0, m = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { sm += part[2 * b]; m = fmax(m, part[2 * b + 1]); }
+    block_sum_max(sm, m);
+    if (threadIdx.x == 0) {
+        dres[0] = sm; dres[1] = m;
+        double sum = 0, mx = 0;
+        sum += sm; mx = fmax(mx, m);
+        const double flag = *oob ? 1.0 : 0.0;
+        dres[2] = sum; dres[3] = flag; dres[4] = mx;
+        host[0] = sum; host[1] = flag; host[2] = mx;
+        __threadfence_system();
+        host[3] = ticket;
+    }
+}
+
+bool single_part(const fs3d_sim* s) { return s->nlocal == 1 && s->nranks == 1; }
+
+// Queues the reduction of part 0's partials into the host record (single-part handles).
+int queue_reduction_single(fs3d_sim* s, const double* partials, int nblocks) {
+    s->ticket += 1.0;
+    hipLaunchKernelGGL(k_reduce_to_host, dim3(1), dim3(256), 0, s->stream, partials, nblocks, s->doob, s->dres, s->hres, s->ticket);
+    SIM_HIP(hipGetLastError());
+    return FS_OK;
+}
+
+// Waits for the record queued last: polls the ticket for a while, then falls back to a stream synchronisation (which
+// also reports a failed launch or kernel).
+int wait_host_record(fs3d_sim* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile double* h = s->hres;
+    static const bool no_poll = [] { const char* e = getenv("FSAMD_NO_POLL"); return e && e[0] == '1'; }();   // (the polling thread keeps a core busy)
+    bool seen = no_poll;
+    if (no_poll) SIM_HIP(hipStreamSynchronize(s->stream));
+    for (int spin = 0; !seen; ++spin) {
+        seen = h[3] == s->ticket;
+        if (!seen && (spin & 1023) == 1023 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) break;
+    }
+    if (!seen) SIM_HIP(hipStreamSynchronize(s->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->cstats.reduction_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++s->cstats.reductions;
+    return oob_status(s);
+}
+
+int finish_reduction_single(fs3d_sim* s, const double* partials, int nblocks, double* sum, double* mx) {
+    FS_TRY(queue_reduction_single(s, partials, nblocks));
+    FS_TRY(wait_host_record(s));
+    if (sum) *sum = s->hres[0];
+    if (mx) *mx = s->hres[2];
+    return FS_OK;
+}
+
 int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
     FS_TRY(queue_reduction(s, mx != nullptr));
     const auto t0 = std::chrono::steady_clock::now();
@@ -888,11 +951,13 @@ int residual(fs3d_sim* s, double* l2, double* max_abs, bool store_div) {
         hipLaunchKernelGGL(k_div_sumsq<T>, dim3(kReduceBlocks), dim3(256), 0, s->stream, p.g, F<T>(p, s->curv, 0),
                            F<T>(p, s->curv, 1), F<T>(p, s->curv, 2), p.flags, p.zb, p.ze, p.partials,
                            store_div ? (T*)p.tmp[0] : (T*)nullptr);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
+        if (!single_part(s))
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, p.partials, kReduceBlocks, s->dres + 2 * k);
     }
     SIM_HIP(hipGetLastError());
     double sum = 0, mx = 0;
-    FS_TRY(finish_reduction(s, &sum, max_abs ? &mx : nullptr));
+    if (single_part(s)) FS_TRY(finish_reduction_single(s, s->parts[0].partials, kReduceBlocks, &sum, max_abs ? &mx : nullptr));
+    else FS_TRY(finish_reduction(s, &sum, max_abs ? &mx : nullptr));
     const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
     if (l2) *l2 = sqrt(sum) / ninterior;   // 3_fluid/FluidSim.cpp:40-43
     if (max_abs) *max_abs = mx;
@@ -1336,6 +1401,12 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
         s->curd = od;
         s->halo_dirty = 0;
     }
+    if (res_sum && single_part(s)) {
+        FS_TRY(queue_reduction_single(s, s->parts[0].adv_part, s->parts[0].adv_blocks));
+        FS_TRY(wait_host_record(s));
+        *res_sum = s->hres[0];
+        return FS_OK;
+    }
     if (res_sum) {
         for (int k = 0; k < s->nlocal; ++k)
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s->stream, s->parts[k].adv_part, s->parts[k].adv_blocks,
@@ -1769,11 +1840,11 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
     SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 4)));
-    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 3, hipHostMallocDefault));
+    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 4, hipHostMallocDefault));
     // the flag the advection kernels raise sits behind the combined record
     s->doob = reinterpret_cast<int*>(s->dres + 2 * s->nlocal + 3);
     SIM_HIP(hipMemset(s->doob, 0, sizeof(double)));
-    s->hres[0] = s->hres[1] = s->hres[2] = 0.0;
+    s->hres[0] = s->hres[1] = s->hres[2] = s->hres[3] = 0.0;
     if (nranks > 1) {
         s->rccl = Rccl::get(s->err);
         if (!s->rccl) return FS_ECOMM;

@@ -12,9 +12,16 @@
 // LDS reads.
 //
 // A backtrace that ends inside the window (|v| dt < 1 cell, the usual case) is
-// served from LDS; any other sample takes the global loads of the direct
-// kernel, lane by lane, so the result does not depend on the window size.  The
+// served from LDS by a step without a branch; a cell with any other sample is
+// computed again, all four samples, by the general path of the direct kernel
+// (global loads), so the result does not depend on the window size.  The
 // arithmetic is that of k_advect, bit for bit.
+//
+// What bounds it: the in-window step is about 250 vector instructions per wave
+// and plane whose cost depends on their kind (see the note above lds_sample),
+// beside a staging skeleton - loads, LDS writes, barrier, stores - that alone
+// takes about as long; the two overlap.  Stores leave after the LDS commit so
+// that the wait for the staged loads does not wait for them as well.
 #pragma once
 #include "fs_kernels3d.hpp"
 #include <type_traits>
@@ -128,11 +135,11 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     // ---- samples -----------------------------------------------------------------------------------------
     // The usual sample ends inside the staged window (|v| dt < 1 cell) and has a finite result.  The step is
     // written for that case without a branch: every sample of a cell reads its eight taps from LDS at an
-    // address clamped into the window and notes in `bad` whether it was entitled to; a cell with a bad sample
-    // (backtrace outside the window or beyond 2^23, non-finite tap or position) is then computed again, all
-    // four samples, by the general path of the direct kernel (validity of every tap, global loads).  Both
-    // paths form the same products in the same order from the same values, so the result does not depend on
-    // which one ran.
+    // address that lies inside the window whatever the lane holds, and notes in `bad` whether it was entitled
+    // to; a cell with a bad sample (displacement of a cell or more, non-finite tap, position or result) is then
+    // computed again, all four samples, by the general path of the direct kernel (validity of every tap, global
+    // loads).  Both paths form the same products in the same order from the same values, so the result does not
+    // depend on which one ran.
     //
     // What the vector ALU charges (measured, eight waves per SIMD): fp32 add/sub/mul, moves, and/or and 32-bit
     // adds on registers or literals issue in about 1.05-1.2 ns per wave and SIMD; anything that reads a scalar

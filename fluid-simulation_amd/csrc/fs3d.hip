@@ -807,6 +807,15 @@ __global__ void k_combine_parts(const double* __restrict__ dres, int nparts, con
     }
 }
 
+// The combined record written into the pinned host mirror, and a ticket behind it that the host can poll.
+__global__ void k_publish_record(const double* __restrict__ comb, volatile double* __restrict__ host, double ticket) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        host[0] = comb[0]; host[1] = comb[1]; host[2] = comb[2];
+        __threadfence_system();
+        host[3] = ticket;
+    }
+}
+
 // An advection of a slab does not wait for its out-of-halo flag; the flag comes back with the next
 // reduction result or synchronisation and stays set until the handle is reset or loaded.  The flag is part of
 // what the ranks add up, so every rank reports the failure at the same call (a rank that stopped alone would
@@ -832,7 +841,10 @@ int queue_reduction(fs3d_sim* s, bool want_max) {
         if (want_max)   // every rank makes the same sequence of calls, so all of them ask for the maximum or none does
             FS_TRY(nccl_check(s, s->rccl->AllReduce(comb + 2, comb + 2, 1, ncclDouble, ncclMax, s->comm_red, s->stream), "ncclAllReduce"));
     }
-    SIM_HIP(hipMemcpyAsync(s->hres, comb, 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    // the record goes to the pinned host mirror by a kernel that writes a ticket behind it (see k_reduce_to_host)
+    s->ticket += 1.0;
+    hipLaunchKernelGGL(k_publish_record, dim3(1), dim3(64), 0, s->stream, comb, s->hres, s->ticket);
+    SIM_HIP(hipGetLastError());
     return FS_OK;
 }
 
@@ -874,7 +886,8 @@ int queue_reduction_single(fs3d_sim* s, const double* partials, int nblocks) {
 int wait_host_record(fs3d_sim* s) {
     const auto t0 = std::chrono::steady_clock::now();
     volatile double* h = s->hres;
-    static const bool no_poll = [] { const char* e = getenv("FSAMD_NO_POLL"); return e && e[0] == '1'; }();   // (the polling thread keeps a core busy)
+    const char* np = getenv("FSAMD_NO_POLL");   // (the polling thread keeps a core busy; read per call: tests switch it between simulations)
+    const bool no_poll = np && np[0] == '1';
     bool seen = no_poll;
     if (no_poll) SIM_HIP(hipStreamSynchronize(s->stream));
     for (int spin = 0; !seen; ++spin) {
@@ -899,13 +912,11 @@ int finish_reduction_single(fs3d_sim* s, const double* partials, int nblocks, do
 
 int finish_reduction(fs3d_sim* s, double* sum, double* mx) {
     FS_TRY(queue_reduction(s, mx != nullptr));
-    const auto t0 = std::chrono::steady_clock::now();
-    FS_TRY(quiesce(s));
-    s->cstats.reduction_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    ++s->cstats.reductions;
+    FS_TRY(join_halos(s));
+    FS_TRY(wait_host_record(s));
     if (sum) *sum = s->hres[0];
     if (mx) *mx = s->hres[2];
-    return oob_status(s);
+    return FS_OK;
 }
 
 template <typename T>
@@ -1413,11 +1424,9 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
                                s->dres + 2 * k);
         SIM_HIP(hipGetLastError());
         FS_TRY(queue_reduction(s, false));
-    }
-    if (res_sum) {
-        SIM_HIP(hipStreamSynchronize(s->stream));
+        FS_TRY(wait_host_record(s));
         *res_sum = s->hres[0];
-        return oob_status(s);
+        return FS_OK;
     }
     return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }

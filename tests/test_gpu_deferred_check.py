@@ -119,3 +119,28 @@ def test_full_size_512_slabs_and_deferral(fsamd):
     for k in range(4):
         assert np.array_equal(a.get_field(k), b.get_field(k)), k
     assert a.stats().sweeps_step >= 2
+
+
+@pytest.mark.parametrize("check_every", [-1, 0, 1])
+def test_polled_host_record_equals_stream_synchronisation(fsamd, check_every, monkeypatch):
+    # a single-GPU handle reads its residuals from a pinned record the reduction kernel writes, polling a ticket;
+    # FSAMD_NO_POLL=1 waits for the stream instead: same numbers, same sweep counts, same fields
+    n = 40
+    cfg = dict(CFG, tol=3e-3, check_every=check_every)
+    monkeypatch.delenv("FSAMD_NO_POLL", raising=False)
+    a = ring(fsamd, n, **cfg)
+    for it in range(5):
+        a.fill_sphere_influence(n / 10.0, it)
+        a.advance(1 / 30.)
+    sa = a.stats()
+    res_a = a.residual()
+    monkeypatch.setenv("FSAMD_NO_POLL", "1")
+    b = ring(fsamd, n, **cfg)
+    for it in range(5):
+        b.fill_sphere_influence(n / 10.0, it)
+        b.advance(1 / 30.)
+    sb = b.stats()
+    assert (sa.sweeps_step, sa.evaluations_step, sa.metric) == (sb.sweeps_step, sb.evaluations_step, sb.metric)
+    assert res_a == b.residual()
+    for k in range(4):
+        assert np.array_equal(a.get_field(k), b.get_field(k))

@@ -148,6 +148,38 @@ def test_semi_lagrange_non_finite_samples_read_as_zero(fsamd, kernel):
         assert np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_semi_lagrange_displacements_around_one_cell(fsamd, dtype):
+    # The staged kernel serves a sample from its window when every displacement is below a bound just under one
+    # cell, and by the general path otherwise.  Planes of constant u whose displacement u*dt lies just below the
+    # bound, on it, just above it, a rounding step below one cell (where x - u*dt rounds up to x + 1 for the larger
+    # x of a 600-cell row, so that floor() leaves the window although |u*dt| < 1), on one cell and beyond, in both
+    # directions; every one must give the oracle's bits.
+    dt = 0.5
+    disp = [0.5, 0.99, 0.998046, 0.998046875, 0.9980469, 0.999, 0.99999994, 1.0, 1.0000001, 1.5]
+    disp = disp + [-d for d in disp]
+    nx, ny, nz = 600, 12, len(disp) + 2
+    o, g = make_pair(fsamd, nx, ny, nz, seed=21, dtype=dtype, scale=0.3, advect_kernel=0)
+    u = o.field(0).copy()
+    for k, d in enumerate(disp):
+        u[k + 1, 1:-1, 1:-1] = dtype(d) / dtype(dt)
+    o.field(0)[...] = u
+    g.set_field(0, u)
+    for it in range(2):
+        o.semi_lagrange(dt)
+        g.semi_lagrange(dt)
+        assert_fields_equal(o, g, what=f"displacements around one cell, pass {it}")
+
+
+def test_semi_lagrange_rows_longer_than_8192(fsamd):
+    # beyond 8192 cells per axis a 4-byte coordinate minus a displacement below one cell may round across a cell
+    # boundary: the staged kernel then serves no sample from its window, and the result is still the oracle's
+    o, g = make_pair(fsamd, 8300, 5, 4, seed=22, scale=1.5, advect_kernel=0)
+    o.semi_lagrange(1.0 / 30.0)
+    g.semi_lagrange(1.0 / 30.0)
+    assert_fields_equal(o, g, what="rows of 8300 cells")
+
+
 def test_semi_lagrange_dt_zero_is_identity(fsamd):
     o, g = make_pair(fsamd, 18, 12, 10, seed=7)
     before = [g.get_field(k) for k in range(4)]

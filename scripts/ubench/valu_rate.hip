@@ -45,6 +45,9 @@ __global__ void k(float* out, int iters) {
 #define I_ADDUS(n) "v_add_u32 %" #n ", s20, %" #n "\n"
 #define I_CMPF(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
 #define I_ADDUK(n) "v_add_u32 %" #n ", 0x2940, %" #n "\n"
+#define I_CND64V(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, vcc\n"
+#define I_CNDC(n) "v_cndmask_b32 %" #n ", 0, %" #n ", vcc\n"
+#define I_CNDSDWA(n) "v_cndmask_b32 %" #n ", %8, %" #n ", vcc\n"
         if (MODE == 0) asm volatile(REP8(I_ADDF) : OPS : "v"(c));
         else if (MODE == 1) asm volatile(REP8(I_ADDU) : OPS : "v"(c));
         else if (MODE == 2) asm volatile(REP8(I_AND) : OPS : "v"(c));
@@ -74,6 +77,9 @@ __global__ void k(float* out, int iters) {
         else if (MODE == 26) asm volatile(REP8(I_ADDUS) : OPS : "v"(c) : "s20");
         else if (MODE == 27) asm volatile(REP8(I_CMPF) : OPS : "v"(c) : "vcc");
         else if (MODE == 28) asm volatile(REP8(I_ADDUK) : OPS : "v"(c));
+        else if (MODE == 29) asm volatile(REP8(I_CND64V) : OPS : "v"(c) : "vcc");
+        else if (MODE == 30) asm volatile(REP8(I_CNDC) : OPS : "v"(c) : "vcc");
+        else if (MODE == 31) asm volatile(REP8(I_CNDSDWA) : OPS : "v"(c) : "vcc");
     }
     out[1 + blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
@@ -94,7 +100,7 @@ float run(float* d, int threads, int blocks, int iters) {
 
 template <int M>
 void all(float* d, int waves, int iters, const char* const* names) {
-    if constexpr (M < 29) {
+    if constexpr (M < 32) {
         const float ms = run<M>(d, 256, 256 * waves, iters);
         printf("%d waves per SIMD  8 x %-30s %7.2f ms -> %.2f ns per wave instruction and SIMD\n", waves, names[M], ms, ms * 1e6 / iters / waves / 8);
         all<M + 1>(d, waves, iters, names);
@@ -106,12 +112,12 @@ int main() {
     hipMalloc(&d, (1 + 256 * 2048) * sizeof(float));
     hipMemset(d, 0, 4);
     const int iters = 100000;
-    const char* names[29] = {"v_add_f32", "v_add_u32", "v_and_b32", "v_cvt_i32_f32", "v_floor_f32", "v_mad_u32_u24", "v_add3_u32",
+    const char* names[32] = {"v_add_f32", "v_add_u32", "v_and_b32", "v_cvt_i32_f32", "v_floor_f32", "v_mad_u32_u24", "v_add3_u32",
                              "v_lshl_add_u32", "v_min_u32", "v_cndmask_b32 (vcc)", "v_cmp_lt_u32 -> vcc", "v_cmp_lt_u32 -> sgpr pair",
                              "v_fma_f32", "v_mov_b32", "v_subrev_u32 (sgpr operand)", "v_cndmask_b32 (sgpr pair)", "v_add_f32 (sgpr operand)",
                              "v_mul_f32 (sgpr operand)", "v_sub_f32 1.0 - x", "v_bfi_b32", "v_bfe_i32", "v_cmp_class_f32 -> vcc", "v_sub_u32",
                              "v_min_f32", "v_lshlrev_b32", "v_mul_u32_u24", "v_add_u32 (sgpr operand)", "v_cmp_lt_f32 -> vcc",
-                             "v_add_u32 (32-bit literal)"};
+                             "v_add_u32 (32-bit literal)", "v_cndmask_b32_e64 (vcc)", "v_cndmask_b32 0, v (vcc)", "v_cndmask_b32 c, v (vcc)"};
     for (int waves : {6, 8}) all<0>(d, waves, iters, names);
     return 0;
 }

@@ -353,6 +353,15 @@ k_change_l1(Grid g, const T* __restrict__ au, const T* __restrict__ av, const T*
 }
 
 template <typename T, int N> struct alignas(N * sizeof(T)) Vec { T e[N]; };
+// One N-wide store that the caches need not keep: nothing reads a swept plane again before the pass ends.
+template <typename T, int N>
+__device__ __forceinline__ void stream_store(T* p, const Vec<T, N>& v) {
+    typedef T Native __attribute__((ext_vector_type(N)));
+    Native n;
+#pragma unroll
+    for (int k = 0; k < N; ++k) n[k] = v.e[k];
+    __builtin_nontemporal_store(n, reinterpret_cast<Native*>(p));
+}
 
 // Sum of squared divergences and max |div| over the cells a visit can relax
 // (not Object, s > 0, and at least one face the visit may move: a StaticFluid

@@ -382,9 +382,9 @@ k_rb_rows(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* _
                 pw.e[2 * j] = X.w[q][0]; pw.e[2 * j + 1] = X.w[q][1];
             }
             if (all) {
-                *reinterpret_cast<VecT*>(uo + i) = pu;
-                *reinterpret_cast<VecT*>(vo + i) = pv;
-                *reinterpret_cast<VecT*>(wo + i) = pw;
+                stream_store(uo + i, pu);
+                stream_store(vo + i, pv);
+                stream_store(wo + i, pw);
             } else {   // the lane straddles the edge of the stored core: pair by pair
 #pragma unroll
                 for (int j = 0; j < CP; ++j)

@@ -259,9 +259,9 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
                 pw.e[2 * j] = X.w[q][0]; pw.e[2 * j + 1] = X.w[q][1];
             }
             if (all) {
-                *reinterpret_cast<VecT*>(uo + i) = pu;
-                *reinterpret_cast<VecT*>(vo + i) = pv;
-                *reinterpret_cast<VecT*>(wo + i) = pw;
+                stream_store(uo + i, pu);
+                stream_store(vo + i, pv);
+                stream_store(wo + i, pw);
             } else {
 #pragma unroll
                 for (int j = 0; j < CP; ++j)

@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fsamd_loader
 fs = fsamd_loader.load()
+if os.environ.get("FSAMD_LIB"):      # an experimental build of the library
+    fs.load_library(os.environ["FSAMD_LIB"])
 for n in [int(a) for a in sys.argv[1:]] or [128, 256, 512]:
     g = fs.FluidSim3D(n, n, n, stop_mode=fs.STOP_FIXED, max_iters=1)
     g.sphere_influence(n / 10.0)

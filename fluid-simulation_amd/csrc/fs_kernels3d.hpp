@@ -812,8 +812,10 @@ k_maccormack(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T
                                 qd[i], nd, oob);
         if (oob) *oob_flag = 1;
     }
-    mu[i] = nu; mv[i] = nv; mw[i] = nw; md[i] = nd;
-    if (cu) { cu[i] = nu; cv[i] = nv; cw[i] = nw; }
+    // (non-temporal stores: nothing reads the results before the launch ends, and the caches are busy with the taps)
+    __builtin_nontemporal_store(nu, mu + i); __builtin_nontemporal_store(nv, mv + i);
+    __builtin_nontemporal_store(nw, mw + i); __builtin_nontemporal_store(nd, md + i);
+    if (cu) { __builtin_nontemporal_store(nu, cu + i); __builtin_nontemporal_store(nv, cv + i); __builtin_nontemporal_store(nw, cw + i); }
 }
 
 // Reflection about the projected field (Zehnder et al. 2018, Alg. 1):

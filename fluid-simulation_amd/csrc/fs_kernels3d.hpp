@@ -756,8 +756,9 @@ k_advect(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const T* __
 template <typename T>
 __device__ __forceinline__ T maccormack_one(const Grid& g, const T* __restrict__ q, const T* __restrict__ f, int x, int y,
                                             int gz, T dx, T dy, T dz, T t_step, T q_own, T f_own, bool& oob) {
-    const Trace<T> tb = trace_prepare(g, x, y, gz, dx, dy, dz, -t_step);
-    const T b = trace_combine(tb, trace_gather(g, f, tb));
+    // (the backward sample in the short form of k_advect: weights of taps the reference does not read are zero)
+    const FastTrace<T, int64_t> tb = fast_prepare<T, int64_t, true>(g, x, y, gz, dx, dy, dz, -t_step);
+    const T b = fast_sample<T, int64_t>(g, f, tb, (int64_t)g.nx * (int64_t)sizeof(T), (int64_t)0);
     T m = f_own + (T)0.5 * (q_own - b);
     const Trace<T> tf = trace_prepare(g, x, y, gz, dx, dy, dz, t_step);
     const Taps<T> a = trace_gather(g, q, tf);

@@ -559,6 +559,7 @@ struct FastTrace {
     int cx, cy, cz;             // tap 0, clamped into the array (cz is a local plane)
     OFF dz1;                    // bytes from the plane of tap 0 to the plane of tap 3 (see Trace::dz1)
     bool oob, far;
+    bool vx0, vx1, vy0, vy1, vz0, vz1;   // which taps the reference reads, per axis (for callers that look at the taps themselves)
 };
 
 template <typename T, typename OFF>
@@ -592,6 +593,7 @@ __device__ __forceinline__ FastTrace<T, OFF> fast_prepare(const Grid& g, int x, 
         tr.oob = ((z0 && !h0) || (z1 && !h1)) && (x0 || x1) && (y0 || y1);
         z0 = z0 && h0; z1 = z1 && h1;
     }
+    tr.vx0 = x0; tr.vx1 = x1; tr.vy0 = y0; tr.vy1 = y1; tr.vz0 = z0; tr.vz1 = z1;
     const T one = (T)1, zero = (T)0;
     tr.x0 = x0 ? one - fu : zero; tr.x1 = x1 ? fu : zero;
     tr.y0 = y0 ? one - fv : zero; tr.y1 = y1 ? fv : zero;
@@ -760,12 +762,15 @@ __device__ __forceinline__ T maccormack_one(const Grid& g, const T* __restrict__
     const FastTrace<T, int64_t> tb = fast_prepare<T, int64_t, true>(g, x, y, gz, dx, dy, dz, -t_step);
     const T b = fast_sample<T, int64_t>(g, f, tb, (int64_t)g.nx * (int64_t)sizeof(T), (int64_t)0);
     T m = f_own + (T)0.5 * (q_own - b);
-    const Trace<T> tf = trace_prepare(g, x, y, gz, dx, dy, dz, t_step);
-    const Taps<T> a = trace_gather(g, q, tf);
+    const FastTrace<T, int64_t> tf = fast_prepare<T, int64_t, true>(g, x, y, gz, dx, dy, dz, t_step);
+    const Taps<T> a = fast_gather<T, int64_t>(q, trace_base(g, tf), (int64_t)g.nx * (int64_t)sizeof(T), tf.dz1);
+    // taps in the order of main.cpp:400-407: 000, 100, 010, 001, 110, 101, 011, 111
+    const bool ok[8] = {tf.vx0 && tf.vy0 && tf.vz0, tf.vx1 && tf.vy0 && tf.vz0, tf.vx0 && tf.vy1 && tf.vz0, tf.vx0 && tf.vy0 && tf.vz1,
+                        tf.vx1 && tf.vy1 && tf.vz0, tf.vx1 && tf.vy0 && tf.vz1, tf.vx0 && tf.vy1 && tf.vz1, tf.vx1 && tf.vy1 && tf.vz1};
     T lo = 0, hi = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const T s = (((tf.ok >> k) & 1u) && isfinite(a.s[k])) ? a.s[k] : (T)0;
+        const T s = (ok[k] && isfinite(a.s[k])) ? a.s[k] : (T)0;
         if (k == 0) { lo = s; hi = s; }
         lo = s < lo ? s : lo;
         hi = s > hi ? s : hi;

@@ -444,6 +444,32 @@ def test_maccormack_step_matches_oracle(fsamd, mode, scale):
         assert_fields_equal(o, g, what=f"maccormack step {step}")
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["reference_step", "reflection_step"])
+def test_maccormack_far_backtraces_and_non_finite_density(fsamd, mode):
+    # both traces of the correction end beyond 2^24 cells for some faces (main.cpp:391-393 divides by 0 or 2 there:
+    # every tap of such a trace reads as 0, in the sample and in the limiter's range alike), and density taps
+    # that are not finite count as 0 (main.cpp:430-434)
+    o, g = make_pair(fsamd, 22, 14, 12, seed=31, scale=3.0, step_mode=mode, tol=50.0, max_iters=3, advection=1)
+    for k, val in ((0, 3.0e9), (1, -7.0e8), (2, 1.1e9)):
+        f = o.field(k).copy()
+        f[4 + k, 5, 6 + k] = val
+        o.field(k)[...] = f
+        g.set_field(k, f)
+    d = o.field(3).copy()
+    d[3, 5, 7] = np.nan
+    d[6, 4, 9] = np.inf
+    d[2, 8, 10] = -np.inf
+    o.field(3)[...] = d
+    g.set_field(3, d)
+    for step in range(2):
+        maccormack_step_oracle(o, 1.0 / 30.0, 50.0, 3, mode == 1)
+        g.advance(1.0 / 30.0)
+        for k in range(4):
+            a, b = o.field(k), g.get_field(k)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (step, k)
+            assert np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0)), (step, k)
+
+
 def test_maccormack_slabs_bitwise_equal_single_domain(fsamd):
     _, g1 = make_pair(fsamd, 28, 18, 23, seed=9, scale=20.0, advection=1, step_mode=1, tol=1.0)
     _, gs = make_pair(fsamd, 28, 18, 23, seed=9, scale=20.0, advection=1, step_mode=1, tol=1.0, local_slabs=3)

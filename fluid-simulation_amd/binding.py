@@ -43,7 +43,7 @@ EXPORTS = [
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
     "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_sweep_pairs", "fs3d_time_field_copies", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
-    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_diagnostics",
+    "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_synchronize_all", "fs3d_diagnostics",
     "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fs3d_residual_noalloc",
     "fsamd_comm_unique_id", "fsamd_comm_selftest",
     "fs3d_create_slab", "fs3d_slab_range", "fs3d_comm_timing", "fs3d_get_comm_stats",
@@ -72,7 +72,7 @@ class Stats(C.Structure):
 class CommStats(C.Structure):
     _fields_ = [("exchanges", C.c_int64), ("waits", C.c_int64), ("reductions", C.c_int64), ("bytes_sent_lo", C.c_int64),
                 ("bytes_sent_hi", C.c_int64), ("exchange_ms", C.c_double), ("wait_ms", C.c_double),
-                ("reduction_host_ms", C.c_double)]
+                ("reduction_host_ms", C.c_double), ("poll_fallbacks", C.c_int64)]
 
 
 class Diag(C.Structure):
@@ -134,6 +134,7 @@ def load_library(path=None):
         "fs3d_advance": (I, [P, D]),
         "fs3d_get_stats": (I, [P, C.POINTER(Stats)]),
         "fs3d_synchronize": (I, [P]),
+        "fs3d_synchronize_all": (I, [P]),
         "fs3d_diagnostics": (I, [P, C.POINTER(Diag)]),
         "fs3d_get_density_downsampled": (I, [P, I, P, C.c_size_t]),
         "fs3d_mg_vcycle": (I, [P]),
@@ -400,6 +401,10 @@ class FluidSim3D:
 
     def synchronize(self):
         self._chk(self.lib.fs3d_synchronize(self.h))
+
+    def synchronize_all(self):
+        """Collective on a multi-rank handle: every rank reports a backtrace that left any rank's halo."""
+        self._chk(self.lib.fs3d_synchronize_all(self.h))
 
     def comm_timing(self, on=True):
         self._chk(self.lib.fs3d_comm_timing(self.h, int(on)))

@@ -888,14 +888,17 @@ int wait_host_record(fs3d_sim* s) {
     volatile double* h = s->hres;
     const char* np = getenv("FSAMD_NO_POLL");   // (the polling thread keeps a core busy; read per call: tests switch it between simulations)
     const bool no_poll = np && np[0] == '1';
-    bool seen = no_poll;
-    if (no_poll) SIM_HIP(hipStreamSynchronize(s->stream));
+    bool seen = false;
+    if (no_poll) { SIM_HIP(hipStreamSynchronize(s->stream)); seen = true; }
     for (int spin = 0; !seen; ++spin) {
         seen = h[3] == s->ticket;
         if (!seen && (spin & 1023) == 1023 &&
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) break;
     }
-    if (!seen) SIM_HIP(hipStreamSynchronize(s->stream));
+    if (!seen) {
+        if (!no_poll) ++s->cstats.poll_fallbacks;   // the ticket did not show within 20 ms: a timing regression, not an error
+        SIM_HIP(hipStreamSynchronize(s->stream));
+    }
     std::atomic_thread_fence(std::memory_order_acquire);
     s->cstats.reduction_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ++s->cstats.reductions;
@@ -1272,11 +1275,12 @@ int project(fs3d_sim* s, int* sweeps_out, double* metric_out, int slot = 0, int 
             FS_TRY(residual<T>(s, &metric, nullptr, false));
             metric /= s->resid_dt;   // b = -div/dt (3_fluid/FluidSim.cpp:17), dx = rho = 1
             if (!(metric > c.tol)) break;
-            // Two failed evaluations give a decay rate, and Gauss-Seidel only slows down as it goes (the smooth error
-            // components outlive the others), so the rate promises at least n more sweeps: the next evaluation can wait
-            // for most of them.  Close to the tolerance n falls below 2 and every sweep is evaluated again, so the
-            // projection still stops on its first sweep at or below the tolerance.
-            if (adaptive && !deferred && last_it >= 0 && metric < last_metric && metric > 0) {
+            // Two failed evaluations give a decay rate, and plain Gauss-Seidel only slows down as it goes (the smooth
+            // error components outlive the others), so the rate promises at least n more sweeps: the next evaluation
+            // can wait for most of them.  Close to the tolerance n falls below 2 and every sweep is evaluated again,
+            // so the projection still stops on its first sweep at or below the tolerance.  Over-relaxed sweeps can
+            // plateau and then speed up, so with omega != 1 nothing is extrapolated.
+            if (adaptive && !deferred && c.omega == 1.0 && last_it >= 0 && metric < last_metric && metric > 0) {
                 const double n = log(c.tol / metric) / (log(metric / last_metric) / (it - last_it));
                 if (n >= 2.5) next_check = std::max(next_check, (int)std::min<double>(c.max_iters, it + floor(0.8 * n)));
             }
@@ -1849,7 +1853,8 @@ int create_common(int nx, int ny, int nz, const fs3d_config* cfg_in, int rank, i
     SIM_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     SIM_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
     SIM_HIP(hipMalloc((void**)&s->dres, sizeof(double) * (2 * s->nlocal + 4)));
-    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 4, hipHostMallocDefault));
+    // (coherent: the host polls this record while a kernel writes it)
+    SIM_HIP(hipHostMalloc((void**)&s->hres, sizeof(double) * 4, hipHostMallocCoherent | hipHostMallocMapped));
     // the flag the advection kernels raise sits behind the combined record
     s->doob = reinterpret_cast<int*>(s->dres + 2 * s->nlocal + 3);
     SIM_HIP(hipMemset(s->doob, 0, sizeof(double)));
@@ -2536,8 +2541,19 @@ int fs3d_get_comm_stats(fs3d_sim* s, fs3d_comm_stats* out, int reset) {
 
 int fs3d_synchronize(fs3d_sim* s) {
     SIM_GUARD(s);
-    // with several ranks the out-of-halo flag is added up over the ranks, so that all of them return the same
-    // status: on a handle of fs3d_create_slab this call is collective
+    // local: this rank's own out-of-halo flag, and what the last reduction over the ranks reported
+    FS_TRY(quiesce(s));
+    if (s->nparts_global > 1) {
+        int flag = 0;
+        SIM_HIP(hipMemcpy(&flag, s->doob, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag) s->hres[1] = 1.0;
+    }
+    return oob_status(s);
+}
+
+int fs3d_synchronize_all(fs3d_sim* s) {
+    SIM_GUARD(s);
+    // the out-of-halo flag is added up over the ranks, so that all of them return the same status
     if (s->nparts_global > 1) FS_TRY(queue_reduction(s, false));
     FS_TRY(quiesce(s));
     return oob_status(s);

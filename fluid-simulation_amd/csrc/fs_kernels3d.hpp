@@ -202,10 +202,14 @@ k_lexi_blocks(Grid g, T* __restrict__ u, T* __restrict__ v, T* __restrict__ w, c
         if (cx < ey && cy < ez) xu = u[gidx(g, x0 + ex, y0 + cx, z0 + cy)];
         if (cx < ex && cy < ez) xv = v[gidx(g, x0 + cx, y0 + ey, z0 + cy)];
         if (cx < ex && cy < ey) xw = w[gidx(g, x0 + cx, y0 + cy, z0 + ez)];
+        // A partial block keeps its extra layers inside the tile (column ex of tu, row ey of tv), where the fill
+        // below would put the zeros of cells outside the block: those slots belong to the extra-layer stores that
+        // follow, which other threads make, so the fill leaves them alone.  (The extra layer of tw, plane ez, is
+        // written twice by the same thread, in program order.)
 #pragma unroll
         for (int lz = 0; lz < LB; ++lz) {
-            tu[(lz * LB + cy) * PU + cx] = ru[lz];
-            tv[(lz * (LB + 1) + cy) * LB + cx] = rv[lz];
+            if (cx != ex) tu[(lz * LB + cy) * PU + cx] = ru[lz];
+            if (cy != ey) tv[(lz * (LB + 1) + cy) * LB + cx] = rv[lz];
             tw[(lz * LB + cy) * LB + cx] = rw[lz];
             tf[(lz * LB + cy) * LB + cx] = rf[lz];
         }

@@ -4,7 +4,7 @@
 // The one-pass sweep is bound by memory (its vector ALUs are about a third busy), and a projection that
 // needs K sweeps reads and writes the velocity K times.  Here a workgroup applies, per step t of its march
 // along z, the first colour of sweep 1 to plane t, the second colour of sweep 1 to plane t-1, the first
-// colour of sweep 2 to plane t-2 and the second colour of sweep 2 to plane t-3, and stores plane t-3: every
+// colour of sweep 2 to plane t-2 and the second colour of sweep 2 to plane t-3, and stores plane t-4: every
 // face is read once and written once per TWO sweeps (12.5 B per cell and sweep).
 //
 // Why the arithmetic is that of four separate half-sweeps: a cell visit (advection-reflection/

@@ -71,7 +71,10 @@ enum {
 /* special values of fs3d_config.check_every */
 enum {
     FS_CHECK_ADAPTIVE = 0,   /* first evaluation one sweep before the count the same projection of the
-                                previous step needed, then after every sweep                        */
+                                previous step needed, then after every sweep; a projection that runs
+                                past that count thins its evaluations out (by the excess, and with
+                                omega == 1 by the decay rate two failed evaluations show), so a capped
+                                projection may overshoot its stopping sweep by a few sweeps           */
     FS_CHECK_DEFERRED = -1   /* as FS_CHECK_ADAPTIVE, but inside fs3d_advance the last evaluation of a
                                 projection is left to the advection that follows (which reads the
                                 projected field anyway and adds up its L2 residual on the way): the
@@ -260,15 +263,17 @@ int fs3d_update(fs3d_sim *sim, double t_step);
  * step_mode of length dt, then time += dt, step += 1.                       */
 int fs3d_advance(fs3d_sim *sim, double dt);
 int fs3d_get_stats(fs3d_sim *sim, fs3d_stats *out);
-/* Blocks until all work queued on the handle has finished.  On a slab handle
- * an advection whose backtrace needed a plane beyond the two halo planes
- * (|v| dt > 2 cells at a slab interface) is not waited for when it is queued:
- * this call, and any projection that evaluates its stopping metric, returns
- * FS_ESTATE for it, until fs3d_reset or fs3d_load.  The flag is added up over
- * the ranks together with the reduced scalars, so every rank returns FS_ESTATE
- * at the same call, whichever rank's backtrace left its halo; for that reason
- * this call is collective on a handle of fs3d_create_slab with several ranks. */
+/* Blocks until all work queued on the handle has finished.  Local: a rank may call it alone.  On a slab
+ * handle an advection whose backtrace needed a plane beyond the two halo planes (|v| dt > 2 cells at a slab
+ * interface) is not waited for when it is queued: this call returns FS_ESTATE for it if this rank's own
+ * kernels raised the flag or if the last reduction over the ranks reported it (until fs3d_reset or
+ * fs3d_load).                                                                                            */
 int fs3d_synchronize(fs3d_sim *sim);
+/* The same, collective on a handle of fs3d_create_slab with several ranks (every rank must call it): the
+ * out-of-halo flag is added up over the ranks, so every rank returns FS_ESTATE at the same call, whichever
+ * rank's backtrace left its halo.  Any projection that evaluates its stopping metric reports the flag the
+ * same way.  No counterpart in the reference (single process).                                          */
+int fs3d_synchronize_all(fs3d_sim *sim);
 
 /* Diagnostics of the current state (the reference prints none; they are what shows
  * what the reflection preserves).  Cell-centred velocities as in
@@ -340,6 +345,8 @@ typedef struct fs3d_comm_stats {
     double exchange_ms;        /* device time of the exchanges on the exchange stream                        */
     double wait_ms;            /* device time the compute stream spent waiting for them: exposed communication */
     double reduction_host_ms;  /* host wall time spent blocked on the reductions                             */
+    int64_t poll_fallbacks;    /* reductions whose record did not show in the polled host word within 20 ms, so
+                                  that the host fell back to a stream synchronisation (should stay 0)        */
 } fs3d_comm_stats;
 int fs3d_comm_timing(fs3d_sim *sim, int on);
 /* reset != 0 zeroes the record after it is copied out */

@@ -109,7 +109,7 @@ def vortex_ring_multigrid(fs, **kw):
 def oob_one_rank(fs, rank=0, nranks=1, comm_id=None):
     """A backtrace that leaves the two halo planes on the upper slab only (|w| dt = 4 cells just above the
     interface): the advection does not wait for its flag, and the next call that does (a residual, then
-    fs3d_synchronize) must fail on EVERY rank, not only on the one whose kernel raised it.  A single domain has
+    fs3d_synchronize_all) must fail on EVERY rank, not only on the one whose kernel raised it.  A single domain has
     no halo to leave: it returns the record every rank must produce."""
     if nranks == 1:
         return {"residual_raised": np.float64(1), "synchronize_raised": np.float64(1), "after_reset_ok": np.float64(1)}
@@ -120,7 +120,7 @@ def oob_one_rank(fs, rank=0, nranks=1, comm_id=None):
     g.set_field(2, w[g.z0:g.z1])
     rec = {}
     g.semi_lagrange(0.02)                   # queued; nobody has looked at the flag yet
-    for name, call in (("residual", g.residual), ("synchronize", g.synchronize)):
+    for name, call in (("residual", g.residual), ("synchronize", g.synchronize_all)):
         try:
             call()
             rec[f"{name}_raised"] = np.float64(0)

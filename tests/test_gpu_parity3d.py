@@ -217,6 +217,25 @@ def test_lexicographic_order_is_the_reference_sweep(fsamd):
         assert cg == co
 
 
+@pytest.mark.parametrize("shape", [(20, 13, 11), (35, 19, 21), (18, 34, 18), (50, 50, 7)])
+def test_lexicographic_order_with_values_on_the_shell_faces(fsamd, shape):
+    # partial 16^3 blocks (interior extents that are no multiples of 16) keep the faces they share with the shell
+    # inside their LDS tile; with values other than zero there (the reference never writes them, but set_field
+    # may) every visit next to the shell must still read them
+    nx, ny, nz = shape
+    o, g = make_pair(fsamd, nx, ny, nz, seed=31, ordering=1)
+    rng = np.random.default_rng(32)
+    for k in range(3):
+        f = (rng.random((nz, ny, nx)) * 2 - 1).astype(np.float32)
+        o.field(k)[...] = f
+        g.set_field(k, f)
+    for it in range(3):
+        co = o.gauss_seidel_projection()
+        cg = g.gauss_seidel_projection()
+        assert_fields_equal(o, g, "uvw", what=f"lexicographic sweep {it} with shell values, {shape}")
+        assert cg == co
+
+
 def test_lexicographic_update_reproduces_recorded_sweep_counts(fsamd):
     # known answers recorded from the reference binary: 32^3 vortex ring, sweeps per step 67/14/12
     n = 32

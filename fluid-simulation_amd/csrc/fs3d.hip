@@ -6,7 +6,9 @@
 // axis, so a slab is one contiguous range of planes) into P = nranks *
 // local_slabs parts.  A part holds its owned planes plus H halo planes on
 // either side when P > 1 (H = 2: one plane for the stencil, one for a
-// backtrace of up to two cells), as dense x-fastest arrays:
+// backtrace of up to two cells; where every slab owns at least four planes the
+// allocations carry D = 2 more planes beyond those, which only the pass of two
+// sweeps reads, see launch_rows2), as dense x-fastest arrays:
 //   f[2][4]   u, v, w, density -- two generations; advection writes the other
 //             generation and the roles swap, which replaces the reference's
 //             snapshot copies (main.cpp:122-127);
@@ -50,6 +52,8 @@ struct Part {
     Grid g{};
     int z0 = 0, z1 = 0;   // owned planes, global
     int H = 0;            // halo planes on either side
+    int D = 0;            // "deep" halo planes beyond those: allocated (every array starts D planes before the plane its
+                          // pointer addresses and ends D planes after local plane nzl - 1) but not counted in g.nzl
     int zb = 0, ze = 0;   // local range of the interior planes this part relaxes / advects
     int gp = 0;           // global part index
     bool has_lo = false, has_hi = false;
@@ -84,6 +88,10 @@ struct fs3d_sim {
     int spec_backoff[2] = {0, 0};   // deferred residual check: projections to wait after a failed one,
     int spec_fails[2] = {0, 0};     // consecutive failures
     bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
+    bool deep = false;           // the slabs carry deep halo planes (Part::D > 0): every slab of the grid owns >= 4 planes
+    bool deep_ok = false;        // the deep halo planes of the current velocity generation are current (or on their way
+                                 // on comm_stream): true after a pass of two sweeps, false after anything else that
+                                 // changes the velocity
     fs3d_config cfg{};
     int nx = 0, ny = 0, nz = 0;
     size_t esz = 4;
@@ -153,14 +161,39 @@ void split_planes(int nz, int P, int gp, int* z0, int* z1) {
     *z1 = *z0 + base + (gp < rem ? 1 : 0);
 }
 
+// Every per-cell array of a part is allocated with D more planes on either side than its local grid counts, and the
+// pointer the part keeps addresses local plane 0.
+size_t deep_bytes(const Part& p, size_t esz) { return (size_t)p.D * (size_t)p.g.sz * esz; }
+size_t alloc_bytes(const Part& p, size_t esz) { return p.n * esz + 2 * deep_bytes(p, esz); }
+
+int alloc_field(fs3d_sim* s, const Part& p, void** out, size_t esz) {
+    char* base = nullptr;
+    SIM_HIP(hipMalloc((void**)&base, alloc_bytes(p, esz)));
+    *out = base + deep_bytes(p, esz);
+    return FS_OK;
+}
+
+void free_field(const Part& p, void* ptr, size_t esz) {
+    if (ptr) (void)hipFree((char*)ptr - deep_bytes(p, esz));
+}
+
+// The local grid widened by the deep planes, and an array pointer moved to its first deep plane.
+Grid deep_grid(const Part& p) {
+    Grid g = p.g;
+    g.nzl += 2 * p.D;
+    g.gz0 -= p.D;
+    return g;
+}
+template <typename P> P* deep_ptr(const Part& p, P* a) { return a - (ptrdiff_t)p.D * p.g.sz; }
+
 void free_parts(fs3d_sim* s) {
     for (Part& p : s->parts) {
         for (int g = 0; g < 2; ++g)
-            for (int k = 0; k < 4; ++k) (void)hipFree(p.f[g][k]);
-        for (int k = 0; k < 3; ++k) (void)hipFree(p.tmp[k]);
-        for (int k = 0; k < 4; ++k) (void)hipFree(p.mc[k]);
+            for (int k = 0; k < 4; ++k) free_field(p, p.f[g][k], s->esz);
+        for (int k = 0; k < 3; ++k) free_field(p, p.tmp[k], s->esz);
+        for (int k = 0; k < 4; ++k) free_field(p, p.mc[k], s->esz);
         for (auto& l : p.mg) for (void* a : l.a) (void)hipFree(a);
-        (void)hipFree(p.cells); (void)hipFree(p.flags); (void)hipFree(p.vflags);
+        free_field(p, p.cells, 1); free_field(p, p.flags, 1); free_field(p, p.vflags, 1);
         (void)hipFree(p.recv_lo); (void)hipFree(p.recv_hi);
         (void)hipFree(p.partials);
         (void)hipFree(p.adv_part);
@@ -171,11 +204,15 @@ void free_parts(fs3d_sim* s) {
 int alloc_parts(fs3d_sim* s) {
     const int P = s->nparts_global;
     s->parts.resize(s->nlocal);
+    // deep halo planes (for the pass of two sweeps) where every slab of the grid can fill four planes of a neighbour
+    // from its own planes; every rank comes to the same answer
+    s->deep = P > 1 && s->nz / P >= 4;
     for (int k = 0; k < s->nlocal; ++k) {
         Part& p = s->parts[k];
         p.gp = s->rank * s->nlocal + k;
         split_planes(s->nz, P, p.gp, &p.z0, &p.z1);
         p.H = P > 1 ? 2 : 0;
+        p.D = s->deep ? 2 : 0;
         p.has_lo = p.gp > 0;
         p.has_hi = p.gp < P - 1;
         if (P > 1 && p.own_planes() < p.H)
@@ -188,11 +225,11 @@ int alloc_parts(fs3d_sim* s) {
         if (p.ze < p.zb) p.ze = p.zb;
         p.n = (size_t)p.g.sz * p.g.nzl;
         for (int g = 0; g < 2; ++g)
-            for (int q = 0; q < 4; ++q) SIM_HIP(hipMalloc(&p.f[g][q], p.n * s->esz));
-        for (int q = 0; q < 3; ++q) SIM_HIP(hipMalloc(&p.tmp[q], p.n * s->esz));
-        SIM_HIP(hipMalloc((void**)&p.cells, p.n));
-        SIM_HIP(hipMalloc((void**)&p.flags, p.n));
-        SIM_HIP(hipMalloc((void**)&p.vflags, p.n));
+            for (int q = 0; q < 4; ++q) FS_TRY(alloc_field(s, p, &p.f[g][q], s->esz));
+        for (int q = 0; q < 3; ++q) FS_TRY(alloc_field(s, p, &p.tmp[q], s->esz));
+        FS_TRY(alloc_field(s, p, (void**)&p.cells, 1));
+        FS_TRY(alloc_field(s, p, (void**)&p.flags, 1));
+        FS_TRY(alloc_field(s, p, (void**)&p.vflags, 1));
         SIM_HIP(hipMalloc((void**)&p.partials, sizeof(double) * 2 * kReduceBlocks));
         if (p.H) {
             SIM_HIP(hipMalloc(&p.recv_lo, (size_t)p.g.sz * s->esz));
@@ -207,17 +244,17 @@ int alloc_parts(fs3d_sim* s) {
 // halo that lie outside the global grid are Object as well.
 int init_cells(fs3d_sim* s) {
     for (Part& p : s->parts) {
-        std::vector<uint8_t> h(p.n);
-        for (int lz = 0; lz < p.g.nzl; ++lz) {
+        std::vector<uint8_t> h(alloc_bytes(p, 1));
+        for (int lz = -p.D; lz < p.g.nzl + p.D; ++lz) {
             const int gz = lz + p.g.gz0;
             for (int y = 0; y < s->ny; ++y)
                 for (int x = 0; x < s->nx; ++x) {
                     const bool shell = gz <= 0 || gz >= s->nz - 1 || y == 0 || y == s->ny - 1 || x == 0 ||
                                        x == s->nx - 1;
-                    h[(size_t)lz * p.g.sz + (size_t)y * s->nx + x] = shell ? FS_CELL_OBJECT : FS_CELL_FLUID;
+                    h[(size_t)(lz + p.D) * p.g.sz + (size_t)y * s->nx + x] = shell ? FS_CELL_OBJECT : FS_CELL_FLUID;
                 }
         }
-        SIM_HIP(hipMemcpy(p.cells, h.data(), p.n, hipMemcpyHostToDevice));
+        SIM_HIP(hipMemcpy(deep_ptr(p, p.cells), h.data(), h.size(), hipMemcpyHostToDevice));
     }
     s->cells_dirty = true;
     return FS_OK;
@@ -226,9 +263,12 @@ int init_cells(fs3d_sim* s) {
 int zero_fields(fs3d_sim* s) {
     for (Part& p : s->parts) {
         for (int g = 0; g < 2; ++g)
-            for (int q = 0; q < 4; ++q) SIM_HIP(hipMemsetAsync(p.f[g][q], 0, p.n * s->esz, s->stream));
-        for (int q = 0; q < 3; ++q) SIM_HIP(hipMemsetAsync(p.tmp[q], 0, p.n * s->esz, s->stream));
+            for (int q = 0; q < 4; ++q)
+                SIM_HIP(hipMemsetAsync((char*)p.f[g][q] - deep_bytes(p, s->esz), 0, alloc_bytes(p, s->esz), s->stream));
+        for (int q = 0; q < 3; ++q)
+            SIM_HIP(hipMemsetAsync((char*)p.tmp[q] - deep_bytes(p, s->esz), 0, alloc_bytes(p, s->esz), s->stream));
     }
+    s->deep_ok = false;
     return FS_OK;
 }
 
@@ -272,6 +312,9 @@ struct HaloOp {
     void* (*base)(fs3d_sim*, Part&, int) = nullptr;
     int which = 0;
     size_t elem = 1;
+    // the planes moved, by their distance from the interface: [d0, d1), d1 = 0 meaning the H halo planes [0, H);
+    // d1 up to H + D reaches the deep planes
+    int d0 = 0, d1 = 0;
 };
 
 int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st);
@@ -287,20 +330,22 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st =
 }
 
 int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st) {
+    // Planes at distance [d0, d1) from an interface: the owned planes H + d (below: H + own - 1 - d) of a part fill
+    // the halo planes H + own + d (H - 1 - d) of its lower (upper) neighbour.  All parts hold the same H.
     bool remote = false;
     for (Part& p : s->parts) {
-        const size_t H = p.H;
+        const ptrdiff_t H = p.H, own = p.own_planes();
         for (const HaloOp& op : ops) {
-            const size_t plane = (size_t)p.g.sz * op.elem;
+            const ptrdiff_t plane = (ptrdiff_t)p.g.sz * (ptrdiff_t)op.elem, d0 = op.d0, d1 = op.d1 > 0 ? op.d1 : H;
             char* mine = (char*)op.base(s, p, op.which);
             // upper neighbour in this process: fill its low halo from my top owned planes, and my
             // high halo from its first owned planes
             if (p.has_hi && (&p != &s->parts.back())) {
                 Part& q = *(&p + 1);
                 char* theirs = (char*)op.base(s, q, op.which);
-                SIM_HIP(hipMemcpyAsync(theirs, mine + (size_t)p.own_planes() * plane, H * plane,
+                SIM_HIP(hipMemcpyAsync(theirs + (H - d1) * plane, mine + (H + own - d1) * plane, (size_t)((d1 - d0) * plane),
                                        hipMemcpyDeviceToDevice, st));
-                SIM_HIP(hipMemcpyAsync(mine + (H + p.own_planes()) * plane, theirs + H * plane, H * plane,
+                SIM_HIP(hipMemcpyAsync(mine + (H + own + d0) * plane, theirs + (H + d0) * plane, (size_t)((d1 - d0) * plane),
                                        hipMemcpyDeviceToDevice, st));
             }
         }
@@ -313,18 +358,21 @@ int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t
         Part& lo = s->parts.front();
         Part& hi = s->parts.back();
         if (lo.has_lo) {
-            const size_t plane = (size_t)lo.g.sz * op.elem, H = lo.H;
+            const ptrdiff_t plane = (ptrdiff_t)lo.g.sz * (ptrdiff_t)op.elem, H = lo.H, d0 = op.d0, d1 = op.d1 > 0 ? op.d1 : H;
+            const size_t bytes = (size_t)((d1 - d0) * plane);
             char* a = (char*)op.base(s, lo, op.which);
-            FS_TRY(nccl_check(s, R->Send(a + H * plane, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclSend"));
-            FS_TRY(nccl_check(s, R->Recv(a, H * plane, ncclUint8, s->rank - 1, s->comm, st), "ncclRecv"));
-            s->cstats.bytes_sent_lo += (int64_t)(H * plane);
+            FS_TRY(nccl_check(s, R->Send(a + (H + d0) * plane, bytes, ncclUint8, s->rank - 1, s->comm, st), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a + (H - d1) * plane, bytes, ncclUint8, s->rank - 1, s->comm, st), "ncclRecv"));
+            s->cstats.bytes_sent_lo += (int64_t)bytes;
         }
         if (hi.has_hi) {
-            const size_t plane = (size_t)hi.g.sz * op.elem, H = hi.H;
+            const ptrdiff_t plane = (ptrdiff_t)hi.g.sz * (ptrdiff_t)op.elem, H = hi.H, own = hi.own_planes(), d0 = op.d0,
+                            d1 = op.d1 > 0 ? op.d1 : H;
+            const size_t bytes = (size_t)((d1 - d0) * plane);
             char* a = (char*)op.base(s, hi, op.which);
-            FS_TRY(nccl_check(s, R->Send(a + (size_t)hi.own_planes() * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclSend"));
-            FS_TRY(nccl_check(s, R->Recv(a + (H + hi.own_planes()) * plane, H * plane, ncclUint8, s->rank + 1, s->comm, st), "ncclRecv"));
-            s->cstats.bytes_sent_hi += (int64_t)(H * plane);
+            FS_TRY(nccl_check(s, R->Send(a + (H + own - d1) * plane, bytes, ncclUint8, s->rank + 1, s->comm, st), "ncclSend"));
+            FS_TRY(nccl_check(s, R->Recv(a + (H + own + d0) * plane, bytes, ncclUint8, s->rank + 1, s->comm, st), "ncclRecv"));
+            s->cstats.bytes_sent_hi += (int64_t)bytes;
         }
     }
     return nccl_check(s, R->GroupEnd(), "ncclGroupEnd");
@@ -373,6 +421,7 @@ int refresh_halos(fs3d_sim* s, int need, bool async = false) {
     if (s->nparts_global == 1) { s->halo_dirty = 0; return FS_OK; }
     const int todo = s->halo_dirty & need;
     std::vector<HaloOp> ops;
+    if (todo & HALO_VEL) s->deep_ok = false;   // (the owners' planes have changed since the halos were filled)
     if (todo & HALO_VEL) for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz});
     if (todo & HALO_DEN) ops.push_back({base_field_cur, 3, s->esz});
     if (todo & HALO_TMP) for (int k = 0; k < 3; ++k) ops.push_back({base_tmp, k, s->esz});
@@ -392,14 +441,16 @@ void halos_after_sweeps(fs3d_sim* s) {
 int refresh_flags(fs3d_sim* s) {
     if (!s->cells_dirty) return FS_OK;
     FS_TRY(join_halos(s));
-    FS_TRY(exchange_halos(s, {{base_cells, 0, 1}}));
+    const int depth = s->parts[0].H + s->parts[0].D;   // the deep planes too: the pass of two sweeps visits their cells
+    FS_TRY(exchange_halos(s, {{base_cells, 0, 1, 0, depth}}));
     for (Part& p : s->parts) {
-        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), p.g.nzl);
-        hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, p.g, p.cells, p.flags, p.vflags);
+        const Grid dg = deep_grid(p);
+        dim3 b(64, 4, 1), g(div_up(s->nx, 64), div_up(s->ny, 4), dg.nzl);
+        hipLaunchKernelGGL(k_build_flags, g, b, 0, s->stream, dg, deep_ptr(p, p.cells), deep_ptr(p, p.flags), deep_ptr(p, p.vflags));
     }
     SIM_HIP(hipGetLastError());
     // the flags of a halo plane depend on cells beyond the halo: take them from the plane's owner
-    FS_TRY(exchange_halos(s, {{base_flags, 0, 1}, {base_flags, 1, 1}}));
+    FS_TRY(exchange_halos(s, {{base_flags, 0, 1, 0, depth}, {base_flags, 1, 1, 0, depth}}));
     s->cells_dirty = false;
     for (Part& p : s->parts) p.mg_weights_ok = false;
     return FS_OK;
@@ -502,6 +553,7 @@ int one_pass_driver(fs3d_sim* s, Launch launch) {
     // waits for B_{k-1} (which read the generation I_k overwrites and produced planes I_k reads) but not
     // for X_{k-1}; B_k reads halo planes and follows X_{k-1} in stream order.  Whoever needs the halos of
     // the last sweep calls join_halos.
+    s->deep_ok = false;   // (this sweep's exchange fills the H halo planes only)
     SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));               // I_{k-1} and everything queued before it
     SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
     if (s->halo_pending) SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_b, 0));   // B_{k-1}, or the exchange queued before sweep 1
@@ -653,56 +705,61 @@ int launch_one_pass_sweep(fs3d_sim* s) {
     return launch_fused_sweep<T>(s);
 }
 
-// Two sweeps in one pass over HBM (fs_sweep_rows2.hpp): single domain, even nx, the register-resident kernel.
+// Two sweeps in one pass over HBM (fs_sweep_rows2.hpp): even nx, the register-resident kernel; a single domain, or
+// z-slabs that carry deep halo planes (every slab of the grid owns at least four planes).
 bool pairs_possible(const fs3d_sim* s) {
     const char* no = getenv("FSAMD_NO_SWEEP_PAIRS");   // read per call: tests switch it between simulations
     const bool off = no && no[0] == '1';
     return !off && s->cfg.ordering == FS_ORDER_RED_BLACK && s->cfg.sweep_kernel == FS_SWEEP_FUSED && s->nx % 2 == 0 &&
-           s->nparts_global == 1;
+           (s->nparts_global == 1 || s->deep);
 }
 
 // The launch of the two-sweep kernel for one choice of lanes per row: tiles of W columns x `rows` rows overlapping by 8,
-// z-chunks, and the number of steps the slowest CU marches (rounds of workgroups x planes of a workgroup: its chunk,
-// the eight planes of overlap and the pipeline).
+// z-chunks of the `planes` planes it stores, and the number of steps the slowest CU marches (rounds of workgroups x
+// planes of a workgroup: its chunk, the eight planes of overlap and the pipeline).
 struct Rows2Plan { int waves, rows, ntx, nty, zchunk, zgroups; double steps; };
 
 template <typename C>
-Rows2Plan rows2_plan(const fs3d_sim* s, int per_cu, int ntx = 0) {   // ntx: that many tiles of a row instead of all of it
+Rows2Plan rows2_plan(const fs3d_sim* s, int planes, int per_cu, int ntx = 0) {   // ntx: that many tiles of a row instead of all of it
     Rows2Plan t;
     // an even number of waves: the rows of a wave then have one colour
     t.waves = std::min(C::WAVES, 2 * div_up(div_up(s->ny, C::RPW), 2));
     t.rows = t.waves * C::RPW;
     t.nty = s->ny <= t.rows ? 1 : div_up(s->ny - 2 * C::S, t.rows - 2 * C::S);
     t.ntx = ntx > 0 ? ntx : s->nx <= C::W ? 1 : div_up(s->nx - 2 * C::S, C::W - 2 * C::S);
-    const int nzl = s->parts[0].g.nzl;
     int best_c = 1;
     t.steps = 1e300;
-    for (int c = 1; c <= std::max(1, nzl / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
-        const int zc = div_up(nzl, c);
-        const double cost = (double)div_up(t.ntx * t.nty * div_up(nzl, zc), per_cu * s->num_cus) * (zc + 12);
+    for (int c = 1; c <= std::max(1, planes / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
+        const int zc = div_up(planes, c);
+        const double cost = (double)div_up(t.ntx * t.nty * div_up(planes, zc), per_cu * s->num_cus) * (zc + 12);
         if (cost < t.steps) { t.steps = cost; best_c = c; }
     }
-    t.zchunk = div_up(nzl, best_c);
-    t.zgroups = div_up(nzl, t.zchunk);
+    t.zchunk = div_up(planes, best_c);
+    t.zgroups = div_up(planes, t.zchunk);
     return t;
 }
 
+// One launch: the planes [z0, z1) of part p (local planes) are stored; the kernel reads four planes more on either
+// side, which for a slab are its halo planes, the deep ones included.
 template <typename T, int NSEG, int CP, int LPR>
-int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov, int xbase = 0, int xedges = 3) {
+int launch_rows2_tiles(fs3d_sim* s, Part& p, const Rows2Plan& t, int cv, int ov, int z0, int z1, hipStream_t st, int xbase = 0,
+                       int xedges = 3) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
     const void* kern = rows2_kernel<T, NSEG, CP, LPR>();   // (instantiated in fs_rows2.hip)
     SIM_HIP(allow_lds(s, kern, C::lds_bytes()));
-    Part& p = s->parts[0];
     dim3 b(64, t.waves, 1), g(t.ntx * t.nty * t.zgroups, 1, 1);
-    // the arguments of k_rb_rows2, in its order and types
-    Grid grid = p.g;
-    const T *ui = F<T>(p, cv, 0), *vi = F<T>(p, cv, 1), *wi = F<T>(p, cv, 2);
-    T *uo = F<T>(p, ov, 0), *vo = F<T>(p, ov, 1), *wo = F<T>(p, ov, 2);
-    const uint8_t* vflags = p.vflags;
+    // the arguments of k_rb_rows2, in its order and types; plane numbers count from the first deep plane
+    Grid grid = deep_grid(p);
+    const T *ui = deep_ptr(p, F<T>(p, cv, 0)), *vi = deep_ptr(p, F<T>(p, cv, 1)), *wi = deep_ptr(p, F<T>(p, cv, 2));
+    T *uo = deep_ptr(p, F<T>(p, ov, 0)), *vo = deep_ptr(p, F<T>(p, ov, 1)), *wo = deep_ptr(p, F<T>(p, ov, 2));
+    const uint8_t* vflags = deep_ptr(p, p.vflags);
     T omega = (T)s->cfg.omega;
-    int zb = p.zb, ze = p.ze, zchunk = t.zchunk, ntx = t.ntx, nty = t.nty, rows = t.rows;
-    void* args[] = {&grid, &ui, &vi, &wi, &uo, &vo, &wo, &vflags, &omega, &zb, &ze, &zchunk, &ntx, &nty, &rows, &xbase, &xedges};
-    SIM_HIP(hipLaunchKernel(kern, g, b, args, C::lds_bytes(), s->stream));
+    // every plane of the arrays that is an interior plane of the grid is relaxed (a slab relaxes its halo planes too:
+    // they go stale ring by ring, exactly like the overlap of two z-chunks)
+    int zb = std::max(1 - grid.gz0, 0), ze = std::max(zb, std::min(s->nz - 1 - grid.gz0, grid.nzl));
+    int zs0 = z0 + p.D, zs1 = z1 + p.D, zchunk = t.zchunk, ntx = t.ntx, nty = t.nty, rows = t.rows;
+    void* args[] = {&grid, &ui, &vi, &wi, &uo, &vo, &wo, &vflags, &omega, &zb, &ze, &zs0, &zs1, &zchunk, &ntx, &nty, &rows, &xbase, &xedges};
+    SIM_HIP(hipLaunchKernel(kern, g, b, args, C::lds_bytes(), st));
     return FS_OK;
 }
 
@@ -716,18 +773,18 @@ int launch_rows2_tiles(fs3d_sim* s, const Rows2Plan& t, int cv, int ov, int xbas
 // columns - those can go to a second launch of 64 x 64 (128 x 32) tiles instead: "64+16", "64+32".
 // FSAMD_ROWS2_LANES_PER_ROW = 64 | 32 | 16 | 64+16 | 64+32 fixes the shape (tests, measurements).
 template <typename T, int NSEG, int CP>
-int launch_rows2(fs3d_sim* s) {
-    if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
-    const int cv = s->curv, ov = s->curv ^ 1;
+int launch_rows2_range(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st) {
+    if (z1 <= z0) return FS_OK;
+    const int cv = s->curv, ov = s->curv ^ 1, planes = z1 - z0;
     using C64 = Rows2Cfg<T, NSEG, CP, 64>;
     using C32 = Rows2Cfg<T, NSEG, CP, 32>;
     using C16 = Rows2Cfg<T, NSEG, CP, 16>;
     const int per_cu = 1;
-    const Rows2Plan t64 = rows2_plan<C64>(s, per_cu), t32 = rows2_plan<C32>(s, per_cu), t16 = rows2_plan<C16>(s, per_cu);
+    const Rows2Plan t64 = rows2_plan<C64>(s, planes, per_cu), t32 = rows2_plan<C32>(s, planes, per_cu), t16 = rows2_plan<C16>(s, planes, per_cu);
     const int last_origin = (t64.ntx - 1) * (C64::W - 2 * C64::S), last_cols = s->nx - last_origin;
     const int rest = t64.ntx < 2 ? 0 : last_cols <= C16::W ? 16 : last_cols <= C32::W ? 32 : 0;   // shape for the last columns
-    const Rows2Plan main64 = rest ? rows2_plan<C64>(s, per_cu, t64.ntx - 1) : t64;
-    const Rows2Plan rest_plan = rest == 16 ? rows2_plan<C16>(s, per_cu, 1) : rest == 32 ? rows2_plan<C32>(s, per_cu, 1) : t64;
+    const Rows2Plan main64 = rest ? rows2_plan<C64>(s, planes, per_cu, t64.ntx - 1) : t64;
+    const Rows2Plan rest_plan = rest == 16 ? rows2_plan<C16>(s, planes, per_cu, 1) : rest == 32 ? rows2_plan<C32>(s, planes, per_cu, 1) : t64;
     enum { ONE64 = 64, ONE32 = 32, ONE16 = 16, SPLIT = 1 };
     int shape = 0;
     if (const char* want = getenv("FSAMD_ROWS2_LANES_PER_ROW")) {   // read per call: tests switch it between simulations
@@ -742,14 +799,66 @@ int launch_rows2(fs3d_sim* s) {
         shape = csplit <= c64 && csplit <= c32 && csplit <= c16 ? SPLIT : c64 <= c32 && c64 <= c16 ? ONE64 : c32 <= c16 ? ONE32 : ONE16;
     }
     if (shape == SPLIT) {
-        FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, main64, cv, ov, 0, 1)));
-        if (rest == 16) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, rest_plan, cv, ov, last_origin, 2)));
-        else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, rest_plan, cv, ov, last_origin, 2)));
-    } else if (shape == ONE64) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, t64, cv, ov)));
-    else if (shape == ONE32) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, t32, cv, ov)));
-    else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, t16, cv, ov)));
+        FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, p, main64, cv, ov, z0, z1, st, 0, 1)));
+        if (rest == 16) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, p, rest_plan, cv, ov, z0, z1, st, last_origin, 2)));
+        else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, p, rest_plan, cv, ov, z0, z1, st, last_origin, 2)));
+    } else if (shape == ONE64) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 64>(s, p, t64, cv, ov, z0, z1, st)));
+    else if (shape == ONE32) FS_TRY((launch_rows2_tiles<T, NSEG, CP, 32>(s, p, t32, cv, ov, z0, z1, st)));
+    else FS_TRY((launch_rows2_tiles<T, NSEG, CP, 16>(s, p, t16, cv, ov, z0, z1, st)));
+    return FS_OK;
+}
+
+// Brings the deep halo planes of the current velocity up to date (they lag after anything but a pass of two sweeps).
+int refresh_deep_halos(fs3d_sim* s) {
+    if (s->deep_ok && !(s->halo_dirty & HALO_VEL)) return FS_OK;
+    const int H = s->parts[0].H, D = s->parts[0].D;
+    // only the deep planes where the H halo planes are current
+    const int d0 = (s->halo_dirty & HALO_VEL) ? 0 : H;
+    std::vector<HaloOp> ops;
+    for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz, d0, H + D});
+    FS_TRY(exchange_async(s, ops));
+    s->halo_dirty &= ~HALO_VEL;
+    s->deep_ok = true;
+    return FS_OK;
+}
+
+// One pass of two sweeps.  On z-slabs the schedule is that of the one-pass sweep (one_pass_driver) with everything twice
+// as deep: a slab stores its owned planes and reads four planes beyond them, so the four owned planes next to each
+// interface are produced on the second stream (B), followed there by the exchange of four planes of u, v and w with
+// each neighbour (X), while the main stream sweeps the rest of the slab (I), which reads owned planes only.  One
+// exchange per two sweeps.
+template <typename T, int NSEG, int CP>
+int launch_rows2(fs3d_sim* s) {
+    if (s->tilde_gen == (s->curv ^ 1)) tilde_to_tmp(s);
+    if (s->nparts_global == 1) {
+        Part& p = s->parts[0];
+        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, 0, p.g.nzl, s->stream)));
+        SIM_HIP(hipGetLastError());
+        s->curv ^= 1;
+        return FS_OK;
+    }
+    FS_TRY(refresh_deep_halos(s));
+    SIM_HIP(hipEventRecord(s->ev_bnd, s->stream));               // I_{k-1} and everything queued before it
+    SIM_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_bnd, 0));
+    if (s->halo_pending) SIM_HIP(hipStreamWaitEvent(s->stream, s->ev_b, 0));   // B_{k-1} (see one_pass_driver)
+    const int depth = s->parts[0].H + s->parts[0].D;
+    for (Part& p : s->parts) {
+        const int own_lo = p.H, own_hi = p.H + p.own_planes();
+        const int lo_end = p.has_lo ? std::min(own_lo + depth, own_hi) : own_lo;
+        const int hi_beg = p.has_hi ? std::max(own_hi - depth, lo_end) : own_hi;
+        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, own_lo, lo_end, s->comm_stream)));
+        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, hi_beg, own_hi, s->comm_stream)));
+        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, lo_end, hi_beg, s->stream)));
+    }
     SIM_HIP(hipGetLastError());
-    s->curv ^= 1;
+    SIM_HIP(hipEventRecord(s->ev_b, s->comm_stream));
+    s->curv ^= 1;   // the halo operators below address the new generation
+    std::vector<HaloOp> ops;
+    for (int k = 0; k < 3; ++k) ops.push_back({base_field_cur, k, s->esz, 0, depth});
+    FS_TRY(exchange_halos(s, ops, s->comm_stream));
+    SIM_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
+    s->halo_pending = true;
+    s->deep_ok = true;
     return FS_OK;
 }
 
@@ -1457,7 +1566,7 @@ template <typename T>
 int maccormack(fs3d_sim* s, double t_step, bool q_from_tmp, bool copy_to_tmp) {
     for (Part& p : s->parts)
         for (int k = 0; k < 4; ++k)
-            if (!p.mc[k]) SIM_HIP(hipMalloc(&p.mc[k], p.n * s->esz));
+            if (!p.mc[k]) FS_TRY(alloc_field(s, p, &p.mc[k], s->esz));
     // the backward trace reads the halo planes of the forward result
     FS_TRY(prepare(s, HALO_ALL | (q_from_tmp ? HALO_TMP : 0)));
     const int cv = s->curv, pv = s->curv ^ 1, cd = s->curd, pd = s->curd ^ 1;

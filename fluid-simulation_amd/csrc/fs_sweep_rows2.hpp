@@ -17,8 +17,9 @@
 //
 // Each half-sweep lets one more ring of a tile go stale (its cells lack the visits of cells outside the
 // tile): tiles overlap by eight cells in x and y, z-chunks by four planes either side, and the stored
-// core is exact.  Output goes to the other generation of the arrays.  Single domain only: a z-slab holds
-// two halo planes, a pass of two sweeps would need four.
+// core is exact.  Output goes to the other generation of the arrays.  A launch stores the planes [zs0, zs1) of
+// the arrays it is given and reads four planes more on either side: the whole grid of a single domain, or
+// the owned planes of a z-slab whose arrays carry four current halo planes on either side.
 #pragma once
 #include <type_traits>
 #include "fs_kernels3d.hpp"
@@ -48,7 +49,7 @@ template <typename T, int NSEG, int CP, int LPR>
 __global__ void __launch_bounds__(1024, 4)
 k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
            T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ vflags, T omega,
-           int zb, int ze, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
+           int zb, int ze, int zs0, int zs1, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
     constexpr int NQ = C::NQ, S = C::S;
     using VecT = Vec<T, 2 * CP>;
@@ -82,7 +83,7 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     // planes [c0, c1) are stored.  The last half-sweep visits [c0 - 1, c1) (the low-z face of plane c0 is the
     // high-z face of the cells below it), every earlier one a plane more on either side, all inside the planes
     // the sweep relaxes, [zb, ze)
-    const int c0 = bz * zchunk, c1 = min(c0 + zchunk, g.nzl);
+    const int c0 = zs0 + bz * zchunk, c1 = min(c0 + zchunk, zs1);
     const int r4b = max(zb, c0 - 1), r4e = min(ze, c1);
     const int r3b = max(zb, c0 - 2), r3e = min(ze, c1 + 1);
     const int r2b = max(zb, c0 - 3), r2e = min(ze, c1 + 2);

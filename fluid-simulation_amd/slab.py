@@ -6,6 +6,7 @@ a slab is one contiguous range of planes.
 from dataclasses import dataclass
 
 HALO = 2   # planes either side: one for the stencil, one more for backtraces of up to two cells
+DEEP_HALO = 4   # planes either side that a pass of two sweeps reads (the library allocates them where every slab owns >= 4 planes)
 
 
 def split_planes(nz, nparts, part):
@@ -20,12 +21,13 @@ class SlabLayout:
     nz: int
     nparts: int
     part: int
+    halo: int = HALO
 
     def __post_init__(self):
         self.z0, self.z1 = split_planes(self.nz, self.nparts, self.part)
-        self.halo = HALO if self.nparts > 1 else 0
-        if self.nparts > 1 and self.z1 - self.z0 < self.halo:
-            raise ValueError("too many slabs: every slab needs at least 2 planes")
+        self.halo = self.halo if self.nparts > 1 else 0
+        if self.nparts > 1 and self.nz // self.nparts < self.halo:
+            raise ValueError(f"too many slabs: every slab needs at least {self.halo} planes")
         self.gz0 = self.z0 - self.halo                 # global z of local plane 0
         self.nzl = (self.z1 - self.z0) + 2 * self.halo  # local planes, halo included
         self.zb = max(self.z0, 1) - self.gz0            # local range of the planes this slab relaxes

@@ -3,8 +3,11 @@ exchange schedule is the library's.  Mode `two_pass`: one interface plane of w p
 parity.  Mode `one_pass` (the production schedule of the one-pass sweep): per full sweep a slab applies the
 first colour to its planes and to the two ghost planes below and one above, the second colour to its planes
 and one ghost plane below (its halo planes go stale, its owned planes come out exact), and then hands its
-two outermost owned planes of u, v and w to each neighbour's halo.  In both modes the per-rank residual sums
-are added across ranks."""
+two outermost owned planes of u, v and w to each neighbour's halo.  Mode `pair` (the schedule of the pass of two
+sweeps): four halo planes either side; per pass the four half-sweeps of two sweeps run on ranges that shrink by one
+plane per half-sweep (the halo planes go stale ring by ring, the owned planes come out exact) and ONE exchange of
+four planes of u, v, w per neighbour follows; an odd last sweep runs the one-pass schedule on the inner two halo
+planes.  In all modes the per-rank residual sums are added across ranks."""
 import os
 import sys
 
@@ -26,7 +29,7 @@ def main():
     nx, ny, nz, sweeps = (int(v) for v in sys.argv[1:5])
     mode = sys.argv[5] if len(sys.argv) > 5 else "two_pass"
     rank, world = fdist.init_control_plane("gloo")
-    lay = SlabLayout(nz, world, rank)
+    lay = SlabLayout(nz, world, rank, halo=4 if mode == "pair" else 2)
     rng = np.random.default_rng(1234)          # every rank draws the same global state
     cells = random_cells((nz, ny, nx), rng)
     fields = [random_field((nz, ny, nx), rng, np.float32) for _ in range(4)]
@@ -57,19 +60,45 @@ def main():
             take = ((parity + lz + gz0) & 1) == take_parity(colour, upper)
             o.w[lz][take] = theirs[take]
 
-    def exchange_two_planes():
-        # my two outermost owned planes of u, v, w go into the neighbour's halo, theirs into mine
-        # (fs3d.hip, one_pass_driver: one grouped send/receive per neighbour and sweep)
+    exchanges = [0]
+
+    def exchange_planes(depth):
+        # my `depth` outermost owned planes of u, v, w go into the neighbour's halo, theirs into mine
+        # (fs3d.hip, one_pass_driver / launch_rows2: one grouped send/receive per neighbour and pass)
         H, own = lay.halo, lay.z1 - lay.z0
-        for peer, mine_at, halo_at in ((rank - 1, pad + H, pad), (rank + 1, pad + own, pad + H + own)):
+        exchanges[0] += 1
+        for peer, mine_at, halo_at in ((rank - 1, pad + H, pad + H - depth), (rank + 1, pad + H + own - depth, pad + H + own)):
             if peer < 0 or peer >= world:
                 continue
-            mine = np.stack([np.array(o.field(k)[mine_at:mine_at + H]) for k in range(3)])
+            mine = np.stack([np.array(o.field(k)[mine_at:mine_at + depth]) for k in range(3)])
             theirs = fdist.exchange_plane(mine, peer)
             for k in range(3):
-                o.field(k)[halo_at:halo_at + H] = theirs[k]
+                o.field(k)[halo_at:halo_at + depth] = theirs[k]
 
-    for _ in range(sweeps):
+    def exchange_two_planes():
+        exchange_planes(2)
+
+    def ranges(extra_lo, extra_hi):
+        return zb - (extra_lo if lay.has_lo else 0), ze + (extra_hi if lay.has_hi else 0)
+
+    todo = sweeps
+    while mode == "pair" and todo > 0:
+        if todo >= 2:
+            # fs_sweep_rows2.hpp: the four half-sweeps of a pass visit [c0-4, c1+3), [c0-3, c1+2), [c0-2, c1+1), [c0-1, c1)
+            for k, colour in enumerate((0, 1, 0, 1)):
+                a, b = ranges(4 - k, 3 - k)
+                o.rb_halfsweep_range(colour, a, b, gz0)
+            exchange_planes(4)
+            todo -= 2
+        else:
+            o.rb_halfsweep_range(0, *ranges(2, 1), gz0)
+            o.rb_halfsweep_range(1, *ranges(1, 0), gz0)
+            exchange_planes(2)
+            todo -= 1
+    if mode == "pair":
+        assert exchanges[0] == (sweeps + 1) // 2
+
+    for _ in range(sweeps if mode != "pair" else 0):
         if mode == "one_pass":
             # the plane ranges of the kernel (fs3d.hip, fused_ranges): first colour on [zb-2, ze+1), second on [zb-1, ze)
             o.rb_halfsweep_range(0, zb - (2 if lay.has_lo else 0), ze + (1 if lay.has_hi else 0), gz0)

@@ -8,8 +8,13 @@
   number of sweeps per projection, enough for neither to be limited by convergence.  What is true, and asserted:
     - with the reference's emitter the system the sweeps solve is incompatible (the StaticFluid sphere's fixed
       faces inject a net flux, and cells whose neighbours are all StaticFluid are skipped, main.cpp:221), so every
-      order settles in its own fixed point; the offset shrinks with the grid: 4.6e-4 at 32^3, 1.1e-4 at 64^3,
-      8e-5 at 128^3.  The 64^3 test bounds it by 2e-4, the 128^3 test by 1e-4;
+      order settles in its own fixed point.  This is a property of ONE projection, not of a hundred steps: from one
+      identical state, swept until one more sweep changes nothing (30 000 sweeps), the lexicographic and the
+      red-black field differ by 1.15e-4 at 64^3 and 4.9e-4 at 32^3 (test_one_projection_has_a_fixed_point_per_order).
+      The offset shrinks with the grid: after 100 steps 4.6e-4 at 32^3, 1.1e-4 at 64^3, 8e-5 at 128^3.  KNOWN MISS:
+      at 64^3 with the emitter the bar of 1e-4 is not met and cannot be by any order other than the reference's
+      own; the 64^3 test pins the measured value (< 1.25e-4) so that a regression shows, the 128^3 and 256^3 tests
+      assert the bar itself;
     - once the emitter is gone (its cells turned into fluid after a blow phase) the bar holds at 64^3: < 1e-4;
 * the divergence the emitter leaves behind however long the sweeps run, bounded and shrinking with the grid.
 Measured values are printed (pytest -s).
@@ -88,7 +93,40 @@ def test_100_steps_red_black_against_lexicographic_64_with_the_emitter(fsamd):
     rb = run_order(fsamd, n, fsamd.ORDER_RED_BLACK, 300, 100)
     d = rel_l2(lexi, rb)
     print(f"\n64^3 vortex ring, 100 steps, 300 sweeps per projection: red-black vs lexicographic rel L2 {d:.3e}")
-    assert 0 < d < 2e-4      # measured 1.1e-4: the emitter's net flux, not a convergence error (1000 sweeps: 1.1e-4 too)
+    # KNOWN MISS of the 1e-4 bar: measured 1.13e-4 (300 and 1000 sweeps per projection alike), the distance between the
+    # two orders' fixed points of a single projection at this size (1.15e-4, see the test below); pinned at +10 %
+    assert 0 < d < 1.25e-4
+
+
+def test_one_projection_has_a_fixed_point_per_order(fsamd):
+    # the decisive experiment behind the miss above: ONE state (the ring after 10 steps, emitter on), one projection
+    # swept to its fixed point in both orders, no advection in between.  The two fields differ by ~1.1e-4 and keep
+    # doing so however long the sweeps run, while one more sweep changes either of them by ~1e-9
+    n = 64
+    g = fsamd.FluidSim3D(n, n, n, stop_mode=fsamd.STOP_FIXED, max_iters=300)
+    g.sphere_influence(n / 10.0)
+    for it in range(10):
+        g.fill_sphere_influence(n / 10.0, it)
+        g.update(DT)
+    cells, start = g.cells, [g.get_field(k) for k in range(4)]
+    g.close()
+    out, last = {}, {}
+    for order in (fsamd.ORDER_LEXICOGRAPHIC, fsamd.ORDER_RED_BLACK):
+        s = fsamd.FluidSim3D(n, n, n, ordering=order, stop_mode=fsamd.STOP_FIXED, max_iters=1)
+        s.set_cell_types(cells)
+        for k in range(4):
+            s.set_field(k, start[k])
+        s.sweeps(4000)
+        mid = [s.get_field(k) for k in range(3)]
+        s.sweeps(2000)
+        out[order] = [s.get_field(k) for k in range(3)]
+        last[order] = rel_l2(mid, out[order])
+        s.close()
+    d = rel_l2(out[fsamd.ORDER_LEXICOGRAPHIC], out[fsamd.ORDER_RED_BLACK])
+    print(f"\n64^3, one projection from one state: fixed points of the two orders differ by rel L2 {d:.3e}; "
+          f"the last 2000 of 6000 sweeps moved them by {last[0]:.1e} / {last[1]:.1e}")
+    assert max(last.values()) < 2e-6      # both have settled ...
+    assert 0.8e-4 < d < 1.5e-4            # ... in two different places
 
 
 def test_100_steps_red_black_against_lexicographic_64_free_ring_meets_1e_4(fsamd):
@@ -112,15 +150,24 @@ def test_100_steps_red_black_against_lexicographic_64_free_ring_meets_1e_4(fsamd
     assert 0 < d < 1e-4      # measured 4.0e-5 (2.8e-5 with 1000 sweeps per projection)
 
 
-def test_red_black_against_lexicographic_128_with_the_emitter_meets_1e_4(fsamd):
-    # one point beyond 64^3 inside the suite's time budget: 30 steps; the 100-step value (8.2e-5 with 1000 sweeps per
-    # projection) is measured by scripts/north_star_table.sh
+def test_100_steps_red_black_against_lexicographic_128_with_the_emitter_meets_1e_4(fsamd):
+    # the bar as stated: 100 steps (the lexicographic order runs as block diagonals, 0.6 ms per sweep at this size)
     n = 128
-    lexi = run_order(fsamd, n, fsamd.ORDER_LEXICOGRAPHIC, 400, 30)
-    rb = run_order(fsamd, n, fsamd.ORDER_RED_BLACK, 400, 30)
+    lexi = run_order(fsamd, n, fsamd.ORDER_LEXICOGRAPHIC, 400, 100)
+    rb = run_order(fsamd, n, fsamd.ORDER_RED_BLACK, 400, 100)
     d = rel_l2(lexi, rb)
-    print(f"\n128^3 vortex ring, 30 steps, 400 sweeps per projection: red-black vs lexicographic rel L2 {d:.3e}")
-    assert 0 < d < 1e-4      # measured 8.2e-5
+    print(f"\n128^3 vortex ring, 100 steps, 400 sweeps per projection: red-black vs lexicographic rel L2 {d:.3e}")
+    assert 0 < d < 1e-4      # measured 8.2e-5 with 1000 sweeps per projection
+
+
+def test_red_black_against_lexicographic_256_headline_size_meets_1e_4(fsamd):
+    # the size the benchmark is quoted on: 30 steps at a fixed 300 sweeps per projection in both orders
+    n = 256
+    lexi = run_order(fsamd, n, fsamd.ORDER_LEXICOGRAPHIC, 300, 30)
+    rb = run_order(fsamd, n, fsamd.ORDER_RED_BLACK, 300, 30)
+    d = rel_l2(lexi, rb)
+    print(f"\n256^3 vortex ring, 30 steps, 300 sweeps per projection: red-black vs lexicographic rel L2 {d:.3e}")
+    assert 0 < d < 1e-4
 
 
 def converged_floor(fsamd, n, sweeps):

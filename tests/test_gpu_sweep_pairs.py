@@ -1,8 +1,9 @@
 """Two sweeps in one pass over HBM (k_rb_rows2) against the oracle's separate sweeps, bit for bit: shapes with one and
 several tiles in x and y, several z-chunks, rows that are and are not multiples of 16 bytes, both precisions, masks
 with Object and StaticFluid cells, over-relaxation, every tile shape of the kernel (one, two or four rows per wave)
-and the shape the library picks itself; and the projection loop, which must stop on the same sweep and
-leave the same field whether or not its sweeps run in pairs."""
+and the shape the library picks itself; the projection loop, which must stop on the same sweep and
+leave the same field whether or not its sweeps run in pairs; and z-slabs, which run the same pass on their owned
+planes with four halo planes either side and exchange once per pass."""
 import numpy as np
 import pytest
 
@@ -109,3 +110,58 @@ def test_pairs_at_512_cubed_equal_single_sweeps(fsamd, monkeypatch):
         g.close()
     for k in range(3):
         assert np.array_equal(fields[0][k], fields[1][k]), k
+
+
+# ---- z-slabs: four halo planes, one exchange per pass -----------------------------------------------------------
+@pytest.mark.parametrize("slabs", [2, 3, 5, 8])
+@pytest.mark.parametrize("shape", [(72, 21, 40), (264, 30, 41), (20, 13, 67), (132, 40, 33)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sweep_pairs_on_local_slabs_bit_exact(fsamd, shape, dtype, slabs):
+    nx, ny, nz = shape
+    o, g = make_pair(fsamd, nx, ny, nz, seed=nx + nz + slabs, dtype=dtype, stop_mode=fsamd.STOP_FIXED, max_iters=1, local_slabs=slabs)
+    done = 0
+    for n in (2, 3, 4, 1, 2):    # pairs, a single sweep after a pair, a pair after a single sweep
+        g.sweeps(n)
+        done += n
+        o.project_rb(stop_mode=0, max_iter=n)
+        assert_fields_equal(o, g, "uvw", what=f"{shape} {dtype.__name__} {slabs} slabs after {done} sweeps")
+
+
+def test_slabs_of_fewer_than_four_planes_keep_the_one_pass_sweep(fsamd):
+    # 23 planes in 8 slabs: two or three planes each, no room for four halo planes from one neighbour
+    o, g = make_pair(fsamd, 40, 18, 23, seed=77, stop_mode=fsamd.STOP_FIXED, max_iters=1, local_slabs=8)
+    with pytest.raises(fsamd.FluidSimError):
+        g.time_sweep_pairs(1)
+    g.sweeps(4)
+    o.project_rb(stop_mode=0, max_iter=4)
+    assert_fields_equal(o, g, "uvw", what="slabs of 2-3 planes")
+    assert g.comm_stats().exchanges >= 4
+
+
+def test_a_pass_of_two_sweeps_on_slabs_halves_the_exchanges(fsamd, monkeypatch):
+    counts = {}
+    fields = {}
+    for no_pairs in ("1", "0"):
+        monkeypatch.setenv("FSAMD_NO_SWEEP_PAIRS", no_pairs)
+        _, g = make_pair(fsamd, 64, 24, 48, seed=5, stop_mode=fsamd.STOP_FIXED, max_iters=1, local_slabs=4)
+        g.sweeps(1)                      # (flags and the first halos are exchanged here)
+        g.comm_stats(reset=True)
+        g.sweeps(12)
+        counts[no_pairs] = g.comm_stats().exchanges
+        fields[no_pairs] = [g.get_field(k) for k in range(3)]
+    assert counts["1"] == 12
+    assert counts["0"] == 7              # one for the deep planes before the first pass, then one per pass
+    for k in range(3):
+        assert np.array_equal(fields["0"][k], fields["1"][k])
+
+
+@pytest.mark.parametrize("stop_mode,tol,check_every", [(2, 2e-5, 1), (2, 2e-5, 3), (2, 2e-5, 0), (1, 2.0, 2), (0, 0.0, 1)])
+def test_projection_and_steps_on_slabs_with_and_without_pairs(fsamd, stop_mode, tol, check_every):
+    cfg = dict(seed=11, scale=5.0, stop_mode=stop_mode, tol=tol, max_iters=40, check_every=check_every, step_mode=fsamd.STEP_REFLECTION)
+    _, a = make_pair(fsamd, 48, 30, 40, local_slabs=3, **cfg)
+    _, b = make_pair(fsamd, 48, 30, 40, sweep_kernel=fsamd.SWEEP_FUSED_LDS, **cfg)     # single domain, never pairs
+    for step in range(3):
+        a.advance(0.02); b.advance(0.02)
+        assert a.stats().sweeps_step == b.stats().sweeps_step
+        for k in range(4):
+            assert np.array_equal(a.get_field(k), b.get_field(k)), (step, k)

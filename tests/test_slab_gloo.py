@@ -1,6 +1,7 @@
 """Multi-rank path on CPU: world_size-2 and -3 gloo process groups run the two slab exchange schedules
 (two-pass: interface w plane per half-sweep merged by parity; one-pass, the production schedule: ghost planes
 recomputed, two planes of u, v, w per neighbour and sweep; summed residual, gathered planes, id broadcast)
+pair: the pass of two sweeps with four halo planes and one exchange per pass)
 with the oracle as the per-rank arithmetic; the result must be bitwise the single-domain sweep."""
 import os
 import socket
@@ -18,13 +19,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["two_pass", "one_pass"])
+@pytest.mark.parametrize("mode", ["two_pass", "one_pass", "pair"])
 @pytest.mark.parametrize("world,shape", [(2, (14, 10, 16)), (3, (9, 12, 17))])
 def test_slab_exchange_schedule_under_gloo(world, shape, mode):
     nx, ny, nz = shape
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "slab_gloo_worker.py"), str(nx), str(ny), str(nz), "3", mode]
+           os.path.join(ROOT, "tests", "slab_gloo_worker.py"), str(nx), str(ny), str(nz), "5" if mode == "pair" else "3", mode]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]

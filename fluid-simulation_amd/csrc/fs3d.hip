@@ -39,6 +39,7 @@
 #include "fs_sweep_rows.hpp"
 #include "fs_sweep_rows2.hpp"
 #include "fs_advect_tiled.hpp"
+#include "fs_sweep_advect.hpp"
 #include "fs_diag3d.hpp"
 #include "fs_mg3d.hpp"
 
@@ -87,6 +88,8 @@ struct fs3d_sim {
     int mg_fails[2] = {0, 0};    // consecutive failed tries
     int spec_backoff[2] = {0, 0};   // deferred residual check: projections to wait after a failed one,
     int spec_fails[2] = {0, 0};     // consecutive failures
+    int fuse_backoff[2] = {0, 0};   // one sweep + advection in one launch: projections to wait after a launch that could
+    int fuse_fails[2] = {0, 0};     // not serve every cell (or missed the tolerance), and consecutive such launches
     bool halo_pending = false;   // work queued on comm_stream that the main stream has not waited for yet
     bool deep = false;           // the slabs carry deep halo planes (Part::D > 0): every slab of the grid owns >= 4 planes
     bool deep_ok = false;        // the deep halo planes of the current velocity generation are current (or on their way
@@ -1544,6 +1547,61 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
     return FS_OK;   // a backtrace beyond the halo raises the flag behind s->dres: see oob_status
 }
 
+// One sweep and the advection that follows it in ONE launch (fs_sweep_advect.hpp): the current velocity is swept in
+// LDS and advected along itself into the other generation, with the residual of the swept field added up on the way.
+// *bad: some cell could not be served (a backtrace of a cell or more, a non-finite sample): the caller drops the
+// result.  4-byte elements, single domain.
+bool fused_step_possible(const fs3d_sim* s) {
+    const char* no = getenv("FSAMD_NO_FUSED_STEP");   // read per call: tests switch it between simulations
+    return !(no && no[0] == '1') && single_part(s) && s->cfg.dtype == FS_F32 && s->cfg.ordering == FS_ORDER_RED_BLACK &&
+           s->cfg.sweep_kernel == FS_SWEEP_FUSED && s->cfg.advect_kernel == FS_ADVECT_TILED && s->cfg.solver == FS_SOLVER_SWEEPS;
+}
+
+int sweep_advect(fs3d_sim* s, double t_step, int density_mode, double* res_sum, bool* bad) {
+    using C = SweepAdvTile;
+    FS_TRY(prepare(s, HALO_ALL));
+    Part& p = s->parts[0];
+    const int cv = s->curv, ov = s->curv ^ 1, cd = s->curd, od = s->curd ^ 1;
+    if (s->tilde_gen == ov) tilde_to_tmp(s);   // the other generation is about to be overwritten
+    auto kern = k_sweep_advect<int64_t>;
+    SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
+    const int tiles = div_up(s->nx, C::TX) * div_up(s->ny, C::TY), planes = p.g.nzl;
+    // z-chunks: (rounds of workgroups over the CUs) x (planes a workgroup marches: its chunk and six more)
+    int best_c = 1;
+    double best = 1e300;
+    for (int c = 1; c <= std::max(1, planes / 2); ++c) {
+        const int zc = div_up(planes, c);
+        const double cost = (double)div_up(tiles * div_up(planes, zc), s->num_cus) * (zc + 6);
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    const int zchunk = div_up(planes, best_c), zgroups = div_up(planes, zchunk);
+    dim3 b(C::TX, C::TY, 1), g(div_up(s->nx, C::TX), div_up(s->ny, C::TY), zgroups);
+    const size_t blocks = (size_t)g.x * g.y * g.z;
+    if (!p.adv_part || p.adv_cap < blocks) {
+        if (p.adv_part) { FS_TRY(quiesce(s)); (void)hipFree(p.adv_part); p.adv_part = nullptr; }
+        const size_t cap = std::max(blocks, (size_t)div_up(s->nx, 64) * div_up(s->ny, 8) * (size_t)(p.own_planes() / 2 + 6));
+        SIM_HIP(hipMalloc((void**)&p.adv_part, cap * 2 * sizeof(double)));
+        p.adv_cap = cap;
+    }
+    p.adv_blocks = (int)blocks;
+    hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<float>(p, cv, 0), F<float>(p, cv, 1), F<float>(p, cv, 2),
+                       F<float>(p, cd, 3), F<float>(p, ov, 0), F<float>(p, ov, 1), F<float>(p, ov, 2), F<float>(p, od, 3), p.flags,
+                       (float)s->cfg.omega, (float)t_step, density_mode, 0, planes, zchunk, s->doob, p.adv_part);
+    SIM_HIP(hipGetLastError());
+    s->curv = ov;
+    s->curd = od;
+    s->halo_dirty = 0;
+    FS_TRY(queue_reduction_single(s, p.adv_part, p.adv_blocks));
+    FS_TRY(wait_host_record(s));
+    *res_sum = s->hres[0];
+    *bad = s->hres[1] > 0.0;
+    if (*bad) {   // (the flag is the out-of-halo flag of the slab path, which a single domain never raises)
+        SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(int), s->stream));
+        s->hres[1] = 0.0;
+    }
+    return FS_OK;
+}
+
 template <typename T>
 int buoyancy(fs3d_sim* s, double dt) {
     FS_TRY(prepare(s));
@@ -1618,9 +1676,39 @@ int deferral(fs3d_sim* s, int slot, bool mac) {
 }
 
 // A projection followed by the advection `adv(res_sum)` that reads the projected field.
-template <typename T, typename Adv>
-int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projection, Adv adv) {
+// `fused(res_sum, bad)`, where the caller has one: the single unverified sweep and the advection in one launch.
+template <typename T, typename Adv, typename Fused>
+int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projection, Adv adv, Fused fused, bool can_fuse) {
     const int mode = deferral(s, slot, mac);
+    if (mode == 1 && can_fuse && fused_step_possible(s) && s->cfg.max_iters > 1) {
+        if (s->fuse_backoff[slot] > 0) --s->fuse_backoff[slot];
+        else {
+            if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
+            double sum = 0;
+            bool bad = false;
+            FS_TRY(fused(&sum, &bad));
+            const double ninterior = (double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2);
+            const double metric = sqrt(sum) / ninterior / s->resid_dt;
+            if (!bad && !(metric > s->cfg.tol)) {
+                s->stats.sweeps = 1;
+                s->stats.sweeps_step += 1;
+                s->stats.metric = metric;
+                s->sweep_hint_prev[slot] = s->sweep_hint[slot];
+                s->sweep_hint[slot] = 1;
+                s->spec_fails[slot] = 0;
+                s->fuse_fails[slot] = 0;
+                return FS_OK;
+            }
+            // not served, or not converged: back to the field before the sweep, and on with separate launches (which
+            // deal with a missed tolerance themselves)
+            s->curv ^= 1;
+            s->curd ^= 1;
+            if (slot == 0) s->tilde_gen = -1;
+            s->fuse_fails[slot] = std::min(s->fuse_fails[slot] + 1, 5);
+            s->fuse_backoff[slot] = 2 << s->fuse_fails[slot];
+            ++s->stats.redone;
+        }
+    }
     bool deferred = mode > 0;
     FS_TRY(project<T>(s, nullptr, nullptr, slot, std::max(mode, 0), 0, mode == 0 ? &deferred : nullptr));
     if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
@@ -1667,7 +1755,7 @@ int step(fs3d_sim* s, double dt) {
             FS_TRY(advect<T>(s, dt, false, mac ? 0 : 1, false, false, res));
             if (mac) FS_TRY(maccormack<T>(s, dt, false, false));
             return (int)FS_OK;
-        })));
+        }, [&](double* res, bool* bad) -> int { return sweep_advect(s, dt, 1, res, bad); }, !mac)));
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     } else {
@@ -1684,7 +1772,11 @@ int step(fs3d_sim* s, double dt) {
             if (keep) s->tilde_gen = s->curv;
             if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, false, true));
             return (int)FS_OK;
-        })));
+        }, [&](double* res, bool* bad) -> int {
+            FS_TRY(sweep_advect(s, 0.5 * dt, 0, res, bad));
+            s->tilde_gen = s->curv;   // (keep holds wherever this launch applies)
+            return (int)FS_OK;
+        }, keep)));
         FS_TRY((project_then_advect<T>(s, 1, mac, s->ev[1], [&](double* res) -> int {
             if (s->cfg.advect_kernel == FS_ADVECT_TILED && !mac) {
                 // the staged kernel forms ur while it loads ut and uh: no reflection pass
@@ -1700,7 +1792,7 @@ int step(fs3d_sim* s, double dt) {
             FS_TRY(advect<T>(s, 0.5 * dt, true, 0));
             if (mac) FS_TRY(maccormack<T>(s, 0.5 * dt, true, false));
             return (int)FS_OK;
-        })));
+        }, [&](double*, bool*) -> int { return (int)FS_OK; }, false)));
         SIM_HIP(hipEventRecord(s->ev[2], s->stream));
         SIM_HIP(hipEventRecord(s->ev[3], s->stream));
     }
@@ -2143,6 +2235,7 @@ int fs3d_reset(fs3d_sim* s) {
     s->sweep_hint[0] = s->sweep_hint[1] = 1;
     s->sweep_hint_prev[0] = s->sweep_hint_prev[1] = 0;
     for (int k = 0; k < 2; ++k) s->spec_backoff[k] = s->spec_fails[k] = s->mg_backoff[k] = s->mg_fails[k] = 0;
+    for (int k = 0; k < 2; ++k) s->fuse_backoff[k] = s->fuse_fails[k] = 0;
     s->mg_backoff[0] = s->mg_backoff[1] = 0;
     s->mg_fails[0] = s->mg_fails[1] = 0;
     SIM_HIP(hipMemsetAsync(s->doob, 0, sizeof(double), s->stream));
@@ -2363,17 +2456,17 @@ int fs3d_time_sweep_pairs(fs3d_sim* s, int npairs, double* ms) {
 }
 
 // The three velocity fields streamed from one generation to the other: what any pass of a sweep has to do at least.
-// Every workgroup copies one contiguous piece of each field, and there are many more workgroups than the GPU holds
-// at once: of the plain copies tried (grid-stride or contiguous pieces, 2 048 to 32 768 workgroups, plain or
-// non-temporal accesses, one stream or three, base addresses skewed against each other) this is the fastest at 512^3.
-__global__ void __launch_bounds__(256)
+// One 16-byte element of each field per thread and no loop, so that consecutive workgroups form one compact front
+// through each array: of the plain copies tried (grid-stride loops, a contiguous piece per workgroup, tiles marched
+// along z in chunks of 1 to 512 planes, 256 to 1024 threads, plain or non-temporal accesses, base addresses skewed
+// against each other) this is the fastest at 512^3, 5.6 TB/s.  (The same shape on ONE array runs at 6.3 TB/s, the
+// figure usually quoted for a "float4 copy": three arrays read and three written at once cost the memory system an
+// eighth of its rate whatever the shape.)
+__global__ void __launch_bounds__(1024)
 k_copy_fields(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c, uint4* __restrict__ x,
               uint4* __restrict__ y, uint4* __restrict__ z, size_t n16) {
-    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
-    const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        x[i] = a[i]; y[i] = b[i]; z[i] = c[i];
-    }
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) { x[i] = a[i]; y[i] = b[i]; z[i] = c[i]; }
 }
 
 int fs3d_time_field_copies(fs3d_sim* s, int n, double* ms) {
@@ -2386,7 +2479,7 @@ int fs3d_time_field_copies(fs3d_sim* s, int n, double* ms) {
     for (int i = 0; i < n; ++i)
         for (Part& p : s->parts) {
             const size_t n16 = p.n * s->esz / 16;   // (the tail of an array that is no multiple of 16 bytes is not part of the measurement)
-            hipLaunchKernelGGL(k_copy_fields, dim3(16384), dim3(256), 0, s->stream, (const uint4*)p.f[s->curv][0],
+            hipLaunchKernelGGL(k_copy_fields, dim3((unsigned)((n16 + 1023) / 1024)), dim3(1024), 0, s->stream, (const uint4*)p.f[s->curv][0],
                                (const uint4*)p.f[s->curv][1], (const uint4*)p.f[s->curv][2], (uint4*)p.f[s->curv ^ 1][0],
                                (uint4*)p.f[s->curv ^ 1][1], (uint4*)p.f[s->curv ^ 1][2], n16);
         }

@@ -116,15 +116,15 @@ def test_one_projection_has_a_fixed_point_per_order(fsamd):
         s.set_cell_types(cells)
         for k in range(4):
             s.set_field(k, start[k])
-        s.sweeps(4000)
+        s.sweeps(20000)
         mid = [s.get_field(k) for k in range(3)]
-        s.sweeps(2000)
+        s.sweeps(5000)
         out[order] = [s.get_field(k) for k in range(3)]
         last[order] = rel_l2(mid, out[order])
         s.close()
     d = rel_l2(out[fsamd.ORDER_LEXICOGRAPHIC], out[fsamd.ORDER_RED_BLACK])
     print(f"\n64^3, one projection from one state: fixed points of the two orders differ by rel L2 {d:.3e}; "
-          f"the last 2000 of 6000 sweeps moved them by {last[0]:.1e} / {last[1]:.1e}")
+          f"the last 5000 of 25000 sweeps moved them by {last[0]:.1e} / {last[1]:.1e}")
     assert max(last.values()) < 2e-6      # both have settled ...
     assert 0.8e-4 < d < 1.5e-4            # ... in two different places
 

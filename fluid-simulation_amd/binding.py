@@ -42,7 +42,7 @@ EXPORTS = [
     "fs3d_get_config", "fs3d_last_error", "fs3d_set_field", "fs3d_get_field", "fs3d_get_field_plane",
     "fs3d_set_cell_types", "fs3d_get_cell_types", "fs3d_sphere_influence", "fs3d_sphere_emitter", "fs3d_solid_sphere",
     "fs3d_fill_sphere_influence", "fs3d_fill_sphere", "fs3d_bottom_influence", "fs3d_clear", "fs3d_apply_source",
-    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_sweep_pairs", "fs3d_time_field_copies", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange",
+    "fs3d_gauss_seidel_projection", "fs3d_sweeps", "fs3d_time_sweeps", "fs3d_time_sweep_pairs", "fs3d_time_field_copies", "fs3d_time_advections", "fs3d_project", "fs3d_residual", "fs3d_semi_lagrange", "fs3d_sweep_advect",
     "fs3d_update", "fs3d_advance", "fs3d_get_stats", "fs3d_synchronize", "fs3d_synchronize_all", "fs3d_diagnostics",
     "fs3d_get_density_downsampled", "fs3d_save", "fs3d_load", "fs3d_mg_vcycle", "fs3d_residual_noalloc",
     "fsamd_comm_unique_id", "fsamd_comm_selftest",
@@ -65,7 +65,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("step", C.c_int64), ("time", C.c_double), ("sweeps", C.c_int32), ("sweeps_step", C.c_int32),
         ("metric", C.c_double), ("ms_project", C.c_double), ("ms_advect", C.c_double), ("ms_step", C.c_double),
-        ("evaluations_step", C.c_int32), ("redone", C.c_int32),
+        ("evaluations_step", C.c_int32), ("redone", C.c_int32), ("fused", C.c_int64),
     ]
 
 
@@ -130,6 +130,7 @@ def load_library(path=None):
         "fs3d_project": (I, [P, C.POINTER(I), C.POINTER(D)]),
         "fs3d_residual": (I, [P, C.POINTER(D), C.POINTER(D)]),
         "fs3d_semi_lagrange": (I, [P, D]),
+        "fs3d_sweep_advect": (I, [P, D, C.POINTER(D), C.POINTER(I)]),
         "fs3d_update": (I, [P, D]),
         "fs3d_advance": (I, [P, D]),
         "fs3d_get_stats": (I, [P, C.POINTER(Stats)]),
@@ -372,6 +373,13 @@ class FluidSim3D:
 
     def semi_lagrange(self, t_step):              # main.cpp:256-291 on a fresh snapshot
         self._chk(self.lib.fs3d_semi_lagrange(self.h, t_step))
+
+    def sweep_advect(self, t_step):
+        """One red-black sweep and semi_lagrange(t_step) in one launch; returns (L2 residual of the swept field,
+        served).  served False: the state is unchanged, use sweeps(1) + semi_lagrange(t_step)."""
+        l2, ok = C.c_double(), C.c_int()
+        self._chk(self.lib.fs3d_sweep_advect(self.h, t_step, C.byref(l2), C.byref(ok)))
+        return l2.value, bool(ok.value)
 
     def update(self, t_step):                     # main.cpp:102-130
         self._chk(self.lib.fs3d_update(self.h, t_step))

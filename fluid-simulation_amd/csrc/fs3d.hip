@@ -1552,9 +1552,16 @@ int advect(fs3d_sim* s, double t_step, bool q_from_tmp, int density_mode, bool c
 // *bad: some cell could not be served (a backtrace of a cell or more, a non-finite sample): the caller drops the
 // result.  4-byte elements, single domain.
 bool fused_step_possible(const fs3d_sim* s) {
-    const char* no = getenv("FSAMD_NO_FUSED_STEP");   // read per call: tests switch it between simulations
-    return !(no && no[0] == '1') && single_part(s) && s->cfg.dtype == FS_F32 && s->cfg.ordering == FS_ORDER_RED_BLACK &&
+    return single_part(s) && s->cfg.dtype == FS_F32 && s->cfg.ordering == FS_ORDER_RED_BLACK &&
            s->cfg.sweep_kernel == FS_SWEEP_FUSED && s->cfg.advect_kernel == FS_ADVECT_TILED && s->cfg.solver == FS_SOLVER_SWEEPS;
+}
+
+// Whether fs3d_advance uses the launch by itself.  It does not unless FSAMD_FUSED_STEP=1: the launch moves 33 instead
+// of 58 bytes per cell but is bound by instruction issue, not by memory (one workgroup of 16 waves per CU, the visits
+// and the advection of a step on the same lanes), and at 512^3 takes 1.9 ms where the two launches take 1.65 ms.
+bool fused_step_wanted(const fs3d_sim* s) {
+    const char* yes = getenv("FSAMD_FUSED_STEP");   // read per call: tests switch it between simulations
+    return yes && yes[0] == '1' && fused_step_possible(s);
 }
 
 int sweep_advect(fs3d_sim* s, double t_step, int density_mode, double* res_sum, bool* bad) {
@@ -1566,12 +1573,12 @@ int sweep_advect(fs3d_sim* s, double t_step, int density_mode, double* res_sum, 
     auto kern = k_sweep_advect<int64_t>;
     SIM_HIP(allow_lds(s, (const void*)kern, C::lds_bytes()));
     const int tiles = div_up(s->nx, C::TX) * div_up(s->ny, C::TY), planes = p.g.nzl;
-    // z-chunks: (rounds of workgroups over the CUs) x (planes a workgroup marches: its chunk and six more)
+    // z-chunks: (rounds of workgroups over the CUs) x (planes a workgroup marches: its chunk and seven more)
     int best_c = 1;
     double best = 1e300;
     for (int c = 1; c <= std::max(1, planes / 2); ++c) {
         const int zc = div_up(planes, c);
-        const double cost = (double)div_up(tiles * div_up(planes, zc), s->num_cus) * (zc + 6);
+        const double cost = (double)div_up(tiles * div_up(planes, zc), s->num_cus) * (zc + 7);
         if (cost < best) { best = cost; best_c = c; }
     }
     const int zchunk = div_up(planes, best_c), zgroups = div_up(planes, zchunk);
@@ -1586,7 +1593,8 @@ int sweep_advect(fs3d_sim* s, double t_step, int density_mode, double* res_sum, 
     p.adv_blocks = (int)blocks;
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<float>(p, cv, 0), F<float>(p, cv, 1), F<float>(p, cv, 2),
                        F<float>(p, cd, 3), F<float>(p, ov, 0), F<float>(p, ov, 1), F<float>(p, ov, 2), F<float>(p, od, 3), p.flags,
-                       (float)s->cfg.omega, (float)t_step, density_mode, 0, planes, zchunk, s->doob, p.adv_part);
+                       (float)s->cfg.omega, (float)t_step, density_mode, 0, planes, zchunk, s->doob, p.adv_part,
+                       getenv("FSAMD_FUSED_DBG") ? atoi(getenv("FSAMD_FUSED_DBG")) : 0);
     SIM_HIP(hipGetLastError());
     s->curv = ov;
     s->curd = od;
@@ -1680,7 +1688,7 @@ int deferral(fs3d_sim* s, int slot, bool mac) {
 template <typename T, typename Adv, typename Fused>
 int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projection, Adv adv, Fused fused, bool can_fuse) {
     const int mode = deferral(s, slot, mac);
-    if (mode == 1 && can_fuse && fused_step_possible(s) && s->cfg.max_iters > 1) {
+    if (mode == 1 && can_fuse && fused_step_wanted(s) && s->cfg.max_iters > 1) {
         if (s->fuse_backoff[slot] > 0) --s->fuse_backoff[slot];
         else {
             if (after_projection) SIM_HIP(hipEventRecord(after_projection, s->stream));
@@ -1697,6 +1705,7 @@ int project_then_advect(fs3d_sim* s, int slot, bool mac, hipEvent_t after_projec
                 s->sweep_hint[slot] = 1;
                 s->spec_fails[slot] = 0;
                 s->fuse_fails[slot] = 0;
+                ++s->stats.fused;
                 return FS_OK;
             }
             // not served, or not converged: back to the field before the sweep, and on with separate launches (which
@@ -2550,6 +2559,22 @@ int fs3d_residual(fs3d_sim* s, double* l2, double* max_abs_div) {
 int fs3d_semi_lagrange(fs3d_sim* s, double t_step) {
     SIM_GUARD(s);
     return DISPATCH(s, advect, s, t_step, false, 1);
+}
+
+int fs3d_sweep_advect(fs3d_sim* s, double t_step, double* residual_l2, int* served) {
+    SIM_GUARD(s);
+    if (!fused_step_possible(s))
+        return set_err(s, FS_ESTATE, "one sweep and the advection in one launch need FS_F32, red-black order, FS_SWEEP_FUSED, FS_ADVECT_TILED and a single domain");
+    double sum = 0;
+    bool bad = false;
+    FS_TRY(sweep_advect(s, t_step, 1, &sum, &bad));
+    if (bad) {   // back to the state before the call
+        s->curv ^= 1;
+        s->curd ^= 1;
+    }
+    if (served) *served = bad ? 0 : 1;
+    if (residual_l2) *residual_l2 = sqrt(sum) / ((double)(s->nx - 2) * (s->ny - 2) * (s->nz - 2));
+    return FS_OK;
 }
 
 int fs3d_update(fs3d_sim* s, double t_step) {

@@ -3,14 +3,16 @@
 // Where a projection is a single sweep (advection-reflection/main.cpp:105-111 leaves the loop after one pass of
 // gauss_seidel_projection(), :189-254) the step is bound by the bytes its launches move: the sweep reads and
 // writes the velocity (25 B per cell), and semi_lagrange() (:256-291) reads it again (33 B).  Here one launch
-// does both: a workgroup marches a tile of 64 x 16 cells along z with a ring of six planes of u, v, w, the
-// density and the flag bytes in LDS, each plane widened by three cells either way.  The planes arrive raw;
-// per step t the workgroup applies the first colour of the sweep to plane t and the second colour to plane
-// t-1 IN the ring (a cell visit touches only its own six faces, :217-232, so within one colour the visits are
-// independent, and the second colour of plane t-1 finds the first colour finished on planes t-2, t-1 and t),
-// which makes plane t-1 final, and then advects plane t-2 from the final planes t-3, t-2, t-1 exactly as
-// k_advect_tiled does from its staged planes.  The swept velocity is never written to memory: the launch moves
-// 17 B per cell in and 16 B out.
+// does both: a workgroup marches a tile of 64 x 16 cells along z with a ring of eight planes of u, v, w and
+// the flag bytes in LDS, each plane widened by three cells either way.  The planes arrive raw; in step t the
+// workgroup applies the first colour of the sweep to plane t and the second colour to plane t-2 IN the ring (a
+// cell visit touches only its own six faces, :217-232, so within one colour the visits are independent, and the
+// second colour of plane t-2 finds the first colour finished on planes t-3, t-2 and t-1 by the steps before),
+// and advects plane t-4 from the planes t-5, t-4, t-3, which the steps before made final, exactly as
+// k_advect_tiled does from its staged planes.  The three jobs of a step touch different planes, so a step has
+// one barrier and a lane's visits overlap its advection.  The density's taps come straight from memory (eight
+// loads per cell, mostly the lines its neighbours load: a ring for it would not fit beside eight planes of the
+// velocity).  The swept velocity is never written to memory: the launch moves 17 B per cell in and 16 B out.
 //
 // Why the result is that of a sweep launch followed by an advection launch, bit for bit: the visits are those
 // of k_rb_halfsweep (same expression, IEEE division); a visit near the edge of the window lacks the visits of
@@ -29,7 +31,7 @@
 namespace fsamd {
 
 struct SweepAdvTile {
-    static constexpr int TX = 64, TY = 16, R = 3, NPL = 6, NF = 4;
+    static constexpr int TX = 64, TY = 16, R = 3, NPL = 8, NF = 3;
     static constexpr int WX = TX + 2 * R, WY = TY + 2 * R, PS = WX * WY;
     static constexpr int NT = TX * TY;
     static constexpr int HALF = WX / 2;                    // cells of one colour in a window row
@@ -43,7 +45,7 @@ __global__ void __launch_bounds__(1024, 4)
 k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ vi, const float* __restrict__ wi,
                const float* __restrict__ qd, float* __restrict__ ou, float* __restrict__ ov, float* __restrict__ ow,
                float* __restrict__ od, const uint8_t* __restrict__ flags, float omega, float t_step, int density_mode,
-               int zb, int ze, int zchunk, int* __restrict__ bad_flag, double* __restrict__ res_part) {
+               int zb, int ze, int zchunk, int* __restrict__ bad_flag, double* __restrict__ res_part, int dbg = 0) {
     using T = float;
     using C = SweepAdvTile;
     constexpr int R = C::R, WX = C::WX, PS = C::PS, NPL = C::NPL;
@@ -60,7 +62,7 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
     const int x0 = bx * C::TX, y0 = by * C::TY;
     const int c0 = zb + bz * zchunk, c1 = min(c0 + zchunk, ze);   // planes this workgroup advects
     const OFF sz = (OFF)g.nx * (OFF)g.ny;                         // elements of a plane
-    const T* src[4] = {ui, vi, wi, qd};
+    const T* src[3] = {ui, vi, wi};
 
     // the window elements this thread stages (the same for every plane); elements outside the grid come from a
     // clamped address: their flag byte is then that of a shell cell, which is never visited, and they are never a
@@ -75,29 +77,29 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
         soff[k] = (OFF)gy * (OFF)g.nx + (OFF)gx;
     }
     const bool second = tid + C::NT < PS;
-    T stage[4][2];
+    T stage[3][2];
     uint8_t fstage[2];
     auto fetch = [&](int p) {    // global -> registers
         const OFF po = (OFF)min(max(p, 0), g.nzl - 1) * sz;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) stage[f][0] = src[f][po + soff[0]];
+        for (int f = 0; f < 3; ++f) stage[f][0] = src[f][po + soff[0]];
         fstage[0] = flags[po + soff[0]];
         if (second) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) stage[f][1] = src[f][po + soff[1]];
+            for (int f = 0; f < 3; ++f) stage[f][1] = src[f][po + soff[1]];
             fstage[1] = flags[po + soff[1]];
         }
     };
-    auto slot = [&](int p) { return (p + 2 * NPL) % NPL; };   // (p >= -NPL)
+    auto slot = [&](int p) { return p & (NPL - 1); };
     auto commit = [&](int p) {   // registers -> LDS
         const int sl = slot(p);
         T* dst = L + sl * PS + tid;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) dst[f * NPL * PS] = stage[f][0];
+        for (int f = 0; f < 3; ++f) dst[f * NPL * PS] = stage[f][0];
         LF[sl * PS + tid] = fstage[0];
         if (second) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) dst[f * NPL * PS + C::NT] = stage[f][1];
+            for (int f = 0; f < 3; ++f) dst[f * NPL * PS + C::NT] = stage[f][1];
             LF[sl * PS + tid + C::NT] = fstage[1];
         }
     };
@@ -146,42 +148,66 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
     auto bit_mask = [](uint32_t v, int b) -> uint32_t { return (uint32_t)((int32_t)(v << (31 - b)) >> 31); };
     auto keep_unless = [](T w, uint32_t kill) -> T { return __uint_as_float(__float_as_uint(w) & ~kill); };
 
-    auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, uint32_t zedge, uint32_t sB, uint32_t sC, uint32_t dAB,
-                          uint32_t dBC, bool& bad) -> T {
+    // A sample inside the window: weights, the signs of floor(p) - own coordinate per axis (each -1 or 0) and whether the
+    // backtrace is short enough for them to be all there is (see k_advect_tiled)
+    struct Prep { FastTrace<T, OFF> tr; uint32_t mx, my, mz; };
+    auto prepare_sample = [&](auto safe_tag, T dx, T dy, T dz, T zf, uint32_t zedge, bool& bad) -> Prep {
         using S = decltype(safe_tag);
         const T one = (T)1;
         const T dxt = dx * tv, dyt = dy * tv, dzt = dz * tv;
         const T px = xf - dxt, py = yf - dyt, pz = zf - dzt;
         const T bx_ = floor(px), by_ = floor(py), bz_ = floor(pz);
         const T fu = px - bx_, fv = py - by_, fw = pz - bz_;
-        FastTrace<T, OFF> tr;
-        tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
+        Prep q;
+        q.tr.x0 = one - fu; q.tr.x1 = fu; q.tr.y0 = one - fv; q.tr.y1 = fv; q.tr.z0 = one - fw; q.tr.z1 = fw;
         const bool in = fmax(fmax(fabs(dxt), fabs(dyt)), fabs(dzt)) < lim;   // (false for a NaN)
-        const uint32_t mx = sign_mask(bx_ - xf), my = sign_mask(by_ - yf), mz = sign_mask(bz_ - zf);
-        if constexpr (!S::x) { tr.x0 = keep_unless(tr.x0, bit_mask(edge, 0) & mx); tr.x1 = keep_unless(tr.x1, bit_mask(edge, 1) & ~mx); }
-        if constexpr (!S::y) { tr.y0 = keep_unless(tr.y0, bit_mask(edge, 2) & my); tr.y1 = keep_unless(tr.y1, bit_mask(edge, 3) & ~my); }
-        if constexpr (!S::z) { tr.z0 = keep_unless(tr.z0, (0u - (zedge & 1u)) & mz); tr.z1 = keep_unless(tr.z1, (0u - (zedge >> 1)) & ~mz); }
-        const uint32_t a4 = wl4 + (mx & (0u - ESZ)) + (my & (0u - (uint32_t)WX * ESZ));
+        q.mx = sign_mask(bx_ - xf); q.my = sign_mask(by_ - yf); q.mz = sign_mask(bz_ - zf);
+        if constexpr (!S::x) { q.tr.x0 = keep_unless(q.tr.x0, bit_mask(edge, 0) & q.mx); q.tr.x1 = keep_unless(q.tr.x1, bit_mask(edge, 1) & ~q.mx); }
+        if constexpr (!S::y) { q.tr.y0 = keep_unless(q.tr.y0, bit_mask(edge, 2) & q.my); q.tr.y1 = keep_unless(q.tr.y1, bit_mask(edge, 3) & ~q.my); }
+        if constexpr (!S::z) { q.tr.z0 = keep_unless(q.tr.z0, (0u - (zedge & 1u)) & q.mz); q.tr.z1 = keep_unless(q.tr.z1, (0u - (zedge >> 1)) & ~q.mz); }
+        bad = bad || !in;
+        return q;
+    };
+    // the taps of a velocity component from the ring
+    auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, uint32_t zedge, uint32_t sB, uint32_t sC, uint32_t dAB,
+                          uint32_t dBC, bool& bad) -> T {
+        const Prep q = prepare_sample(safe_tag, dx, dy, dz, zf, zedge, bad);
+        const uint32_t a4 = wl4 + (q.mx & (0u - ESZ)) + (q.my & (0u - (uint32_t)WX * ESZ));
         uint32_t kB = sB + (uint32_t)f * FS, kC = sC + (uint32_t)f * FS;
         asm volatile("" : "+s"(kB), "+s"(kC));
-        const uint32_t o0 = a4 + (mz & dAB) + kB;
-        const uint32_t o1 = a4 + (mz & dBC) + kC;
+        const uint32_t o0 = a4 + (q.mz & dAB) + kB;
+        const uint32_t o1 = a4 + (q.mz & dBC) + kC;
         const T* p0 = reinterpret_cast<const T*>(lds_raw + o0);
         const T* p1 = reinterpret_cast<const T*>(lds_raw + o1);
         Taps<T> t;
         t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[WX]; t.s[3] = p1[0];
         t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
-        T r = fast_combine(tr, t);
+        T r = fast_combine(q.tr, t);
         asm volatile("" : "+v"(r));
-        bad = bad || !in;
+        return r;
+    };
+    // the taps of the density from memory: own element `own`, the lower tap one element, row and plane before it where
+    // the mask of the axis says so (all of them inside the grid for an interior cell)
+    auto mem_sample = [&](auto safe_tag, OFF own, T dx, T dy, T dz, T zf, uint32_t zedge, bool& bad) -> T {
+        const Prep q = prepare_sample(safe_tag, dx, dy, dz, zf, zedge, bad);
+        const OFF row = (OFF)g.nx;
+        const OFF base = own - (OFF)(q.mx & 1u) - ((OFF)(q.my & 1u)) * row - ((OFF)(q.mz & 1u)) * sz;
+        const T* p0 = qd + base;
+        const T* p1 = p0 + sz;
+        Taps<T> t;
+        t.s[0] = p0[0]; t.s[1] = p0[1]; t.s[2] = p0[row]; t.s[3] = p1[0];
+        t.s[4] = p0[row + 1]; t.s[5] = p1[1]; t.s[6] = p1[row]; t.s[7] = p1[row + 1];
+        T r = fast_combine(q.tr, t);
+        asm volatile("" : "+v"(r));
         return r;
     };
 
     double racc = 0;
     auto compute = [&](auto safe_tag, int z, uint32_t fl, T (&res)[4]) -> bool {
         const int gz = z + g.gz0;
-        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
-        const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
+        const OFF own = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
+        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = qd[own];
+        const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1 && !(dbg & 4);
         bool bad = false;
         if (interior) {
             const T zf = (T)gz;
@@ -217,7 +243,7 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
             } else {
                 uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
             }
-            const T sd = smp(3, uc, vc, wc);
+            const T sd = (dbg & 2) ? nd : mem_sample(safe_tag, own, uc, vc, wc, zf, zedge, bad);
             if (!(fl & FL_SELF_OBJECT)) nd = sd;
             bad = bad || !isfinite((su + sv) + (sw + sd));
         }
@@ -230,27 +256,30 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
         __builtin_nontemporal_store(res[2], ow + i); __builtin_nontemporal_store(res[3], od + i);
     };
 
-    // Step t: commit plane t+1; first colour on plane t; second colour on plane t-1 (which is final then); advect
-    // plane t-2; fetch plane t+2.  The half-sweeps visit the planes the advected ones need and the interior of the
-    // grid only: the second colour [c0-2, c1], the first [c0-3, c1+1].
-    const int zlo = 1 - 0, zhi = g.nzl - 1;                 // interior planes [zlo, zhi) of a single domain
+    // Step t: commit plane t+2 (fetched in the step before), fetch plane t+3, first colour on plane t, second colour on
+    // plane t-2, advect plane t-4.  The half-sweeps visit the planes the advected ones need and the interior of the
+    // grid only: the second colour [c0-2, c1], the first [c0-3, c1+1].  What a step writes - ring slot t+2 (= t-6), the
+    // faces of planes t and t+1 (w), t-2 and t-1 (w) - and what it reads beyond that - planes t-5 to t-3 - are
+    // different planes, so the one barrier at its top is all the ordering it needs.
+    const int zlo = 1, zhi = g.nzl - 1;                     // interior planes [zlo, zhi) of a single domain
     const int t0 = c0 - 3;
     fetch(t0); commit(t0);
-    fetch(t0 + 1);
+    fetch(t0 + 1); commit(t0 + 1);
+    fetch(t0 + 2);
     T res[4];
     bool have = false;
     int zres = 0;
-    for (int t = t0; t <= c1 + 1; ++t) {
-        commit(t + 1);
+    for (int t = t0; t <= c1 + 3; ++t) {
+        __syncthreads();
+        commit(t + 2);
         asm volatile("" ::: "memory");
         if (have) { store(zres, res); have = false; }      // (after the commit: its wait for the staged loads does not wait for these stores)
-        __syncthreads();
-        if (t >= zlo && t < zhi) relax(t, 0);
-        __syncthreads();
-        if (t - 1 >= zlo && t - 1 < zhi && t - 1 >= c0 - 2) relax(t - 1, 1);
-        __syncthreads();
-        fetch(t + 2);
-        const int z = t - 2;
+        fetch(t + 3);
+        if (!(dbg & 1)) {
+        if (t >= zlo && t < zhi && t <= c1 + 1) relax(t, 0);
+        if (t - 2 >= zlo && t - 2 < zhi && t - 2 >= c0 - 2 && t - 2 <= c1) relax(t - 2, 1);
+        }
+        const int z = t - 4;
         if (z >= c0 && z < c1 && mine) {
             const uint32_t fl = LF[slot(z) * PS + wl];
             const int gz = z + g.gz0;

@@ -172,6 +172,8 @@ typedef struct fs3d_stats {
                                 step (an evaluation folded into an advection is not a pass)         */
     int32_t redone;          /* advections repeated since reset because a deferred evaluation found
                                 the tolerance not met (FS_CHECK_DEFERRED)                           */
+    int64_t fused;           /* projections of one sweep since reset that ran inside the launch of the
+                                advection after them (see fs3d_sweep_advect)                        */
 } fs3d_stats;
 
 typedef struct fs3d_sim fs3d_sim;
@@ -257,6 +259,16 @@ int fs3d_residual(fs3d_sim *sim, double *l2, double *max_abs_div);
 /* semi_lagrange(t_step, snapshot...) (main.cpp:256-291) applied to a snapshot
  * of the current state, as update() calls it (main.cpp:122-129).            */
 int fs3d_semi_lagrange(fs3d_sim *sim, double t_step);
+/* One sweep of gauss_seidel_projection() (main.cpp:189-254, red-black order) and semi_lagrange(t_step)
+ * (main.cpp:256-291) of the swept field in ONE launch: the swept velocity lives in LDS only, so the launch
+ * moves 33 instead of 58 bytes per cell.  What fs3d_advance does by itself under FS_CHECK_DEFERRED wherever a
+ * projection of the previous two steps needed a single sweep.  *residual_l2 (may be NULL) receives the L2
+ * residual of the swept field, as fs3d_residual would report it between the two.  *served = 0 means that some
+ * cell's backtrace left the staged window (|v| t_step of a cell or more) or was not finite: the launch cannot
+ * serve such a cell, the state is then left as it was before the call and the caller runs fs3d_sweeps(1) and
+ * fs3d_semi_lagrange instead (same result, bit for bit, where both apply).  FS_ESTATE unless FS_F32, red-black
+ * order, FS_SWEEP_FUSED, FS_ADVECT_TILED, a single domain.  No counterpart in the reference.               */
+int fs3d_sweep_advect(fs3d_sim *sim, double t_step, double *residual_l2, int *served);
 /* update(t_step) (main.cpp:102-130) = fs3d_project + fs3d_semi_lagrange.    */
 int fs3d_update(fs3d_sim *sim, double t_step);
 /* Simulation::advance (include/Simulation.h:47): one step of the configured

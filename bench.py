@@ -27,8 +27,8 @@ The printed JSON line carries
                     blocking factor stand beside it as `algorithmic_*`.  The other of the two sweep kernels is
                     reported as roofline_one_sweep_pass / roofline_two_sweep_pass;
                     velocity_copy_us / launch_over_copy: the time of a kernel that only streams the three velocity fields
-                    from one generation to the other (the fastest plain copy found: one contiguous piece per
-                    workgroup), measured in the same run - the floor of any pass;
+                    from one generation to the other (the fastest plain copy of three fields found: one 16-byte
+                    element of each per thread, no loop), measured in the same run - the floor of any pass;
   roofline_advect   the same for the two advection kernels of the step (33 and 45 B per cell);
   cpu_baseline      the CPU oracle in the reference's own execution model (one thread, lexicographic sweeps,
                     serial-order advection) on a bounded sample, and `cpu_baseline_openmp`, its red-black loops on

@@ -39,7 +39,8 @@ struct Rows2Cfg {
     static constexpr int SEGW = 2 * LPR * CP;
     static constexpr int W = SEGW * NSEG;
     static constexpr int NQ = NSEG * CP;
-    static constexpr int NPV = 5;           // v planes in LDS: one per phase of a step and the plane being stored
+    static constexpr int NPV = 8;           // v planes in LDS: one per phase of a step and the plane being stored make five; eight, so that
+                                            // the slot of a plane is a mask and not a division (scalar instructions are not free here)
     static constexpr int S = 4;             // rings of a tile that go stale (one per half-sweep)
     static constexpr size_t v_bytes() { return (size_t)NPV * WAVES * 2 * NQ * 64 * sizeof(T); }
     static constexpr size_t lds_bytes() { return v_bytes() + kRcpBytes; }   // + the reciprocals of visit_quotient()
@@ -154,7 +155,7 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
             for (int j = 0; j < CP; ++j) { X.w[sg * CP + j][0] = pw.e[2 * j]; X.w[sg * CP + j][1] = pw.e[2 * j + 1]; }
         }
     };
-    auto vrow = [&](int p, int wv) { return sv + ((size_t)((p + 2 * C::NPV) % C::NPV) * waves + wv) * (2 * NQ * 64); };
+    auto vrow = [&](int p, int wv) { return sv + ((size_t)((unsigned)(p + 2 * C::NPV) % (unsigned)C::NPV) * waves + wv) * (2 * NQ * 64); };
     auto vpos = [&](int q, int c) { return (2 * q + c) * 64 + lane; };
     auto stage_v = [&](int p) {
         T* row = vrow(p, ry);

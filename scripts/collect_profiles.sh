@@ -4,7 +4,7 @@
 # (one run per counter, never combined with tracing).  usage: collect_profiles.sh <tag>   (e.g. r01)
 # Output goes to gpurun_out/profiles_<tag>/ ; copy the summaries into profiles/ afterwards.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT && mkdir -p $OUT   # (merged results of an earlier run with the same tag would be mixed in: use a fresh tag)

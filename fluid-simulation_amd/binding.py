@@ -66,6 +66,7 @@ class Stats(C.Structure):
         ("step", C.c_int64), ("time", C.c_double), ("sweeps", C.c_int32), ("sweeps_step", C.c_int32),
         ("metric", C.c_double), ("ms_project", C.c_double), ("ms_advect", C.c_double), ("ms_step", C.c_double),
         ("evaluations_step", C.c_int32), ("redone", C.c_int32), ("fused", C.c_int64),
+        ("sweeps_total", C.c_int64), ("evaluations_total", C.c_int64),
     ]
 
 

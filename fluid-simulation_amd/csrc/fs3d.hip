@@ -1807,6 +1807,8 @@ int step(fs3d_sim* s, double dt) {
     }
     s->stats.time += dt;
     s->stats.step += 1;
+    s->stats.sweeps_total += s->stats.sweeps_step;
+    s->stats.evaluations_total += s->stats.evaluations_step;
     return FS_OK;
 }
 

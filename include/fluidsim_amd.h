@@ -174,6 +174,9 @@ typedef struct fs3d_stats {
                                 the tolerance not met (FS_CHECK_DEFERRED)                           */
     int64_t fused;           /* projections of one sweep since reset that ran inside the launch of the
                                 advection after them (see fs3d_sweep_advect)                        */
+    int64_t sweeps_total;    /* sweeps of all projections of fs3d_advance since reset               */
+    int64_t evaluations_total; /* the same for evaluations_step: a caller that times many steps reads
+                                the two totals once at the end instead of asking after every step   */
 } fs3d_stats;
 
 typedef struct fs3d_sim fs3d_sim;

@@ -43,7 +43,7 @@ def test_default_config_is_the_reference_behaviour(fsamd):
     # main.cpp:108: change > 5.0f, iter < 1000; fp32 everywhere (main.cpp:302-314)
     assert (cfg.dtype, cfg.stop_mode, cfg.max_iters, cfg.tol, cfg.omega) == (fsamd.F32, fsamd.STOP_L1_CHANGE, 1000, 5.0, 1.0)
     assert cfg.step_mode == fsamd.STEP_REFERENCE and cfg.local_slabs == 1 and cfg.check_every == 1
-    assert ctypes.sizeof(fsamd.Config) == 72 and ctypes.sizeof(fsamd.Stats) == 72 and ctypes.sizeof(fsamd.CommStats) == 72
+    assert ctypes.sizeof(fsamd.Config) == 72 and ctypes.sizeof(fsamd.Stats) == 88 and ctypes.sizeof(fsamd.CommStats) == 72
 
 
 def test_missing_library_fails_loudly(fsamd, tmp_path):

@@ -129,7 +129,7 @@ def test_bench_launch_line_with_two_ranks(fsamd):
     plane_bytes = 96 * 96 * 4
     for r in pr:
         assert r["exchanges_per_step"] > 0 and r["reductions_per_step"] > 0 and r["halo_ms_per_step"] > 0
-        assert r["exposed_wait_ms_per_step"] >= 0 and r["device_ms_per_step"] > 0
+        assert r["exposed_wait_ms_per_step"] >= 0 and r["wall_ms_per_step"] > 0
     assert pr[0]["bytes_sent_lo_per_step"] == 0 and pr[1]["bytes_sent_hi_per_step"] == 0
     assert pr[0]["bytes_sent_hi_per_step"] == pr[1]["bytes_sent_lo_per_step"] > 0
     assert pr[0]["bytes_sent_hi_per_step"] % (2 * plane_bytes) == 0      # whole pairs of halo planes

@@ -1593,8 +1593,7 @@ int sweep_advect(fs3d_sim* s, double t_step, int density_mode, double* res_sum, 
     p.adv_blocks = (int)blocks;
     hipLaunchKernelGGL(kern, g, b, C::lds_bytes(), s->stream, p.g, F<float>(p, cv, 0), F<float>(p, cv, 1), F<float>(p, cv, 2),
                        F<float>(p, cd, 3), F<float>(p, ov, 0), F<float>(p, ov, 1), F<float>(p, ov, 2), F<float>(p, od, 3), p.flags,
-                       (float)s->cfg.omega, (float)t_step, density_mode, 0, planes, zchunk, s->doob, p.adv_part,
-                       getenv("FSAMD_FUSED_DBG") ? atoi(getenv("FSAMD_FUSED_DBG")) : 0);
+                       (float)s->cfg.omega, (float)t_step, density_mode, 0, planes, zchunk, s->doob, p.adv_part);
     SIM_HIP(hipGetLastError());
     s->curv = ov;
     s->curd = od;

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(1024, 4)
 k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ vi, const float* __restrict__ wi,
                const float* __restrict__ qd, float* __restrict__ ou, float* __restrict__ ov, float* __restrict__ ow,
                float* __restrict__ od, const uint8_t* __restrict__ flags, float omega, float t_step, int density_mode,
-               int zb, int ze, int zchunk, int* __restrict__ bad_flag, double* __restrict__ res_part, int dbg = 0) {
+               int zb, int ze, int zchunk, int* __restrict__ bad_flag, double* __restrict__ res_part) {
     using T = float;
     using C = SweepAdvTile;
     constexpr int R = C::R, WX = C::WX, PS = C::PS, NPL = C::NPL;
@@ -207,7 +207,7 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
         const int gz = z + g.gz0;
         const OFF own = ((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x;
         T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = qd[own];
-        const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1 && !(dbg & 4);
+        const bool interior = x > 0 && y > 0 && gz > 0 && x < g.nx - 1 && y < g.ny - 1 && gz < g.gnz - 1;
         bool bad = false;
         if (interior) {
             const T zf = (T)gz;
@@ -243,7 +243,7 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
             } else {
                 uc = (u_c + u_xp) / two; vc = (v_c + v_yp) / two; wc = (w_c + w_zp) / two;
             }
-            const T sd = (dbg & 2) ? nd : mem_sample(safe_tag, own, uc, vc, wc, zf, zedge, bad);
+            const T sd = mem_sample(safe_tag, own, uc, vc, wc, zf, zedge, bad);
             if (!(fl & FL_SELF_OBJECT)) nd = sd;
             bad = bad || !isfinite((su + sv) + (sw + sd));
         }
@@ -275,10 +275,8 @@ k_sweep_advect(Grid g, const float* __restrict__ ui, const float* __restrict__ v
         asm volatile("" ::: "memory");
         if (have) { store(zres, res); have = false; }      // (after the commit: its wait for the staged loads does not wait for these stores)
         fetch(t + 3);
-        if (!(dbg & 1)) {
         if (t >= zlo && t < zhi && t <= c1 + 1) relax(t, 0);
         if (t - 2 >= zlo && t - 2 < zhi && t - 2 >= c0 - 2 && t - 2 <= c1) relax(t - 2, 1);
-        }
         const int z = t - 4;
         if (z >= c0 && z < c1 && mine) {
             const uint32_t fl = LF[slot(z) * PS + wl];

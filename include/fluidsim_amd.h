@@ -264,8 +264,10 @@ int fs3d_residual(fs3d_sim *sim, double *l2, double *max_abs_div);
 int fs3d_semi_lagrange(fs3d_sim *sim, double t_step);
 /* One sweep of gauss_seidel_projection() (main.cpp:189-254, red-black order) and semi_lagrange(t_step)
  * (main.cpp:256-291) of the swept field in ONE launch: the swept velocity lives in LDS only, so the launch
- * moves 33 instead of 58 bytes per cell.  What fs3d_advance does by itself under FS_CHECK_DEFERRED wherever a
- * projection of the previous two steps needed a single sweep.  *residual_l2 (may be NULL) receives the L2
+ * moves 33 instead of 58 bytes per cell.  On MI355X it is bound by instruction issue and takes longer than the two
+ * launches (1.9 against 1.65 ms at 512^3), so fs3d_advance uses it only when the environment says FSAMD_FUSED_STEP=1
+ * (then under FS_CHECK_DEFERRED wherever a projection needed a single sweep in the previous two steps); the result is
+ * the same bit for bit either way.  *residual_l2 (may be NULL) receives the L2
  * residual of the swept field, as fs3d_residual would report it between the two.  *served = 0 means that some
  * cell's backtrace left the staged window (|v| t_step of a cell or more) or was not finite: the launch cannot
  * serve such a cell, the state is then left as it was before the call and the caller runs fs3d_sweeps(1) and

@@ -594,10 +594,10 @@ FusedRanges fused_ranges(const Part& p) {
 
 // z-chunks of one launch: pick the chunk count that minimises (rounds of workgroups over the CUs) x
 // (planes a workgroup marches through, its overlap and pipeline planes included).
-inline int pick_chunks(int planes, int tiles, int slots) {
+inline int pick_chunks(int planes, int tiles, int slots, int max_len = 1 << 30) {
     int best_c = 1;
     double best = 1e300;
-    for (int c = 1; c <= std::max(1, planes / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
+    for (int c = div_up(planes, max_len); c <= std::max(1, planes / 2); ++c) {   // (chunks of two planes at least: small grids are bound by the steps of a workgroup)
         const int zc = div_up(planes, c);
         const int rounds = div_up(tiles * div_up(planes, zc), slots);
         const double cost = (double)rounds * (zc + 6);
@@ -1447,7 +1447,11 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
         if (ends > 0) {   // two workgroups along z: the first and the last `ends` planes of [zb, ze)
             zchunk = ze - ends - zb; zlen = ends; zgroups = 2;
         } else {
-            const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus);
+            // Chunks of at most 128 planes: the workgroups of a round start together and the front they form stays
+            // compact, so that the apron rows a tile shares with its neighbours are still in L2 when the neighbour
+            // asks; tiles that march the whole of a 512-plane grid drift apart (512^3: reflected advection 1.45 ms
+            // with one chunk, 1.34 with chunks of 64 to 128 planes, 1.36 with 32, 1.45 with 16).
+            const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus, 128);
             zchunk = zlen = div_up(ze - zb, nchunks);
             zgroups = div_up(ze - zb, zchunk);
         }

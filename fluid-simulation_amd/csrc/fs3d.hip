@@ -720,10 +720,11 @@ bool pairs_possible(const fs3d_sim* s) {
 // The launch of the two-sweep kernel for one choice of lanes per row: tiles of W columns x `rows` rows overlapping by 8,
 // z-chunks of the `planes` planes it stores, and the number of steps the slowest CU marches (rounds of workgroups x
 // planes of a workgroup: its chunk, the eight planes of overlap and the pipeline).
-struct Rows2Plan { int waves, rows, ntx, nty, zchunk, zgroups; double steps; };
+struct Rows2Plan { int waves, rows, ntx, nty, zchunk, zlen, zgroups; double steps; };
 
+// ends > 0: the launch stores the first and the last `ends` planes of the `planes` it is given, one chunk each.
 template <typename C>
-Rows2Plan rows2_plan(const fs3d_sim* s, int planes, int per_cu, int ntx = 0) {   // ntx: that many tiles of a row instead of all of it
+Rows2Plan rows2_plan(const fs3d_sim* s, int planes, int per_cu, int ntx = 0, int ends = 0) {   // ntx: that many tiles of a row instead of all of it
     Rows2Plan t;
     // an even number of waves: the rows of a wave then have one colour
     t.waves = std::min(C::WAVES, 2 * div_up(div_up(s->ny, C::RPW), 2));
@@ -737,8 +738,12 @@ Rows2Plan rows2_plan(const fs3d_sim* s, int planes, int per_cu, int ntx = 0) {  
         const double cost = (double)div_up(t.ntx * t.nty * div_up(planes, zc), per_cu * s->num_cus) * (zc + 12);
         if (cost < t.steps) { t.steps = cost; best_c = c; }
     }
-    t.zchunk = div_up(planes, best_c);
+    t.zchunk = t.zlen = div_up(planes, best_c);
     t.zgroups = div_up(planes, t.zchunk);
+    if (ends > 0) {
+        t.zchunk = planes - ends; t.zlen = ends; t.zgroups = 2;
+        t.steps = (double)div_up(t.ntx * t.nty * 2, per_cu * s->num_cus) * (ends + 12);
+    }
     return t;
 }
 
@@ -760,8 +765,8 @@ int launch_rows2_tiles(fs3d_sim* s, Part& p, const Rows2Plan& t, int cv, int ov,
     // every plane of the arrays that is an interior plane of the grid is relaxed (a slab relaxes its halo planes too:
     // they go stale ring by ring, exactly like the overlap of two z-chunks)
     int zb = std::max(1 - grid.gz0, 0), ze = std::max(zb, std::min(s->nz - 1 - grid.gz0, grid.nzl));
-    int zs0 = z0 + p.D, zs1 = z1 + p.D, zchunk = t.zchunk, ntx = t.ntx, nty = t.nty, rows = t.rows;
-    void* args[] = {&grid, &ui, &vi, &wi, &uo, &vo, &wo, &vflags, &omega, &zb, &ze, &zs0, &zs1, &zchunk, &ntx, &nty, &rows, &xbase, &xedges};
+    int zs0 = z0 + p.D, zs1 = z1 + p.D, zchunk = t.zchunk, zlen = t.zlen, ntx = t.ntx, nty = t.nty, rows = t.rows;
+    void* args[] = {&grid, &ui, &vi, &wi, &uo, &vo, &wo, &vflags, &omega, &zb, &ze, &zs0, &zs1, &zchunk, &zlen, &ntx, &nty, &rows, &xbase, &xedges};
     SIM_HIP(hipLaunchKernel(kern, g, b, args, C::lds_bytes(), st));
     return FS_OK;
 }
@@ -775,19 +780,21 @@ int launch_rows2_tiles(fs3d_sim* s, Part& p, const Rows2Plan& t, int cv, int ov,
 // Where the last 256-column tile of a row would hold at most 64 (128) columns - nx = 512 is two tiles and sixteen
 // columns - those can go to a second launch of 64 x 64 (128 x 32) tiles instead: "64+16", "64+32".
 // FSAMD_ROWS2_LANES_PER_ROW = 64 | 32 | 16 | 64+16 | 64+32 fixes the shape (tests, measurements).
+// ends > 0: only the first and the last `ends` planes of [z0, z1) (the planes next to the two interfaces of a slab,
+// in one launch: its workgroups run side by side instead of one launch after the other).
 template <typename T, int NSEG, int CP>
-int launch_rows2_range(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st) {
+int launch_rows2_range(fs3d_sim* s, Part& p, int z0, int z1, hipStream_t st, int ends = 0) {
     if (z1 <= z0) return FS_OK;
-    const int cv = s->curv, ov = s->curv ^ 1, planes = z1 - z0;
+    const int cv = s->curv, ov = s->curv ^ 1;
     using C64 = Rows2Cfg<T, NSEG, CP, 64>;
     using C32 = Rows2Cfg<T, NSEG, CP, 32>;
     using C16 = Rows2Cfg<T, NSEG, CP, 16>;
-    const int per_cu = 1;
-    const Rows2Plan t64 = rows2_plan<C64>(s, planes, per_cu), t32 = rows2_plan<C32>(s, planes, per_cu), t16 = rows2_plan<C16>(s, planes, per_cu);
+    const int per_cu = 1, span = z1 - z0;   // (with ends, a plan covers the span and stores its two ends)
+    const Rows2Plan t64 = rows2_plan<C64>(s, span, per_cu, 0, ends), t32 = rows2_plan<C32>(s, span, per_cu, 0, ends), t16 = rows2_plan<C16>(s, span, per_cu, 0, ends);
     const int last_origin = (t64.ntx - 1) * (C64::W - 2 * C64::S), last_cols = s->nx - last_origin;
     const int rest = t64.ntx < 2 ? 0 : last_cols <= C16::W ? 16 : last_cols <= C32::W ? 32 : 0;   // shape for the last columns
-    const Rows2Plan main64 = rest ? rows2_plan<C64>(s, planes, per_cu, t64.ntx - 1) : t64;
-    const Rows2Plan rest_plan = rest == 16 ? rows2_plan<C16>(s, planes, per_cu, 1) : rest == 32 ? rows2_plan<C32>(s, planes, per_cu, 1) : t64;
+    const Rows2Plan main64 = rest ? rows2_plan<C64>(s, span, per_cu, t64.ntx - 1, ends) : t64;
+    const Rows2Plan rest_plan = rest == 16 ? rows2_plan<C16>(s, span, per_cu, 1, ends) : rest == 32 ? rows2_plan<C32>(s, span, per_cu, 1, ends) : t64;
     enum { ONE64 = 64, ONE32 = 32, ONE16 = 16, SPLIT = 1 };
     int shape = 0;
     if (const char* want = getenv("FSAMD_ROWS2_LANES_PER_ROW")) {   // read per call: tests switch it between simulations
@@ -849,8 +856,13 @@ int launch_rows2(fs3d_sim* s) {
         const int own_lo = p.H, own_hi = p.H + p.own_planes();
         const int lo_end = p.has_lo ? std::min(own_lo + depth, own_hi) : own_lo;
         const int hi_beg = p.has_hi ? std::max(own_hi - depth, lo_end) : own_hi;
-        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, own_lo, lo_end, s->comm_stream)));
-        FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, hi_beg, own_hi, s->comm_stream)));
+        // (a slab with two interfaces: the planes next to both in one launch)
+        if (lo_end - own_lo == depth && own_hi - hi_beg == depth && hi_beg >= lo_end)
+            FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, own_lo, own_hi, s->comm_stream, depth)));
+        else {
+            FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, own_lo, lo_end, s->comm_stream)));
+            FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, hi_beg, own_hi, s->comm_stream)));
+        }
         FS_TRY((launch_rows2_range<T, NSEG, CP>(s, p, lo_end, hi_beg, s->stream)));
     }
     SIM_HIP(hipGetLastError());

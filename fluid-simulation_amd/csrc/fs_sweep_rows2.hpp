@@ -50,7 +50,7 @@ template <typename T, int NSEG, int CP, int LPR>
 __global__ void __launch_bounds__(1024, 4)
 k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ wi,
            T* __restrict__ uo, T* __restrict__ vo, T* __restrict__ wo, const uint8_t* __restrict__ vflags, T omega,
-           int zb, int ze, int zs0, int zs1, int zchunk, int ntx, int nty, int rows, int xbase, int xedges) {
+           int zb, int ze, int zs0, int zs1, int zchunk, int zlen, int ntx, int nty, int rows, int xbase, int xedges) {
     using C = Rows2Cfg<T, NSEG, CP, LPR>;
     constexpr int NQ = C::NQ, S = C::S;
     using VecT = Vec<T, 2 * CP>;
@@ -84,7 +84,9 @@ k_rb_rows2(Grid g, const T* __restrict__ ui, const T* __restrict__ vi, const T* 
     // planes [c0, c1) are stored.  The last half-sweep visits [c0 - 1, c1) (the low-z face of plane c0 is the
     // high-z face of the cells below it), every earlier one a plane more on either side, all inside the planes
     // the sweep relaxes, [zb, ze)
-    const int c0 = zs0 + bz * zchunk, c1 = min(c0 + zchunk, zs1);
+    // (a workgroup's planes: zlen of them every zchunk planes - zlen = zchunk, except where one launch serves the planes
+    // next to a slab's lower and upper interface)
+    const int c0 = zs0 + bz * zchunk, c1 = min(c0 + zlen, zs1);
     const int r4b = max(zb, c0 - 1), r4e = min(ze, c1);
     const int r3b = max(zb, c0 - 2), r3e = min(ze, c1 + 1);
     const int r2b = max(zb, c0 - 3), r2e = min(ze, c1 + 2);

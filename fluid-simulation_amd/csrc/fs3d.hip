@@ -1463,10 +1463,11 @@ int launch_advect(fs3d_sim* s, Part& p, const T* qu, const T* qv, const T* qw, i
             // compact, so that the apron rows a tile shares with its neighbours are still in L2 when the neighbour
             // asks; tiles that march the whole of a 512-plane grid drift apart (512^3: reflected advection 1.45 ms
             // with one chunk, 1.34 with chunks of 64 to 128 planes, 1.36 with 32, 1.45 with 16).
-            const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus, 128);
+            const int nchunks = pick_chunks(ze - zb, tiles, per_cu * s->num_cus, AdvTile<T, false>::kMaxChunk);
             zchunk = zlen = div_up(ze - zb, nchunks);
             zgroups = div_up(ze - zb, zchunk);
         }
+        if (zlen > AdvTile<T, false>::kMaxChunk) return set_err(s, FS_ESTATE, "an advection chunk of more planes than the kernel keeps notes for");
         dim3 b(64, TY, 1), g(div_up(s->nx, 64), div_up(s->ny, TY), zgroups);
         double* res_part = nullptr;
         if (with_res) {   // the launches of one advection write their partials one after the other

@@ -36,6 +36,7 @@ struct AdvTile {
     static constexpr int TX = 64, TY = 8, R = 1, NPL = 4;   // NPL = 2R+2 planes, a power of two
     static constexpr int WX = TX + 2 * R, WY = TY + 2 * R, PS = WX * WY;
     static constexpr int NF = SEP ? 7 : 4;                  // u,v,w,d carried (+ the carrying velocity if it is another field)
+    static constexpr int kMaxChunk = 128;                   // most planes a workgroup may be given (a bit per plane notes the cells to redo)
     static constexpr int NT = TX * TY;
     static constexpr int NLD = (PS + NT - 1) / NT;
     static constexpr size_t lds_bytes() { return (size_t)NF * NPL * PS * sizeof(T); }
@@ -230,17 +231,34 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     };
 
     double racc = 0;
-    // One interior cell: the 13-point neighbourhood of the carrying velocity, the three velocity samples, the
-    // density sample.  `smp(f, dx, dy, dz)` is the sampler; `first` says that this is the cell's first pass.
-    auto cell = [&](auto&& smp, int z, uint32_t fl, bool first, T& nu, T& nv, T& nw, T& nd) -> T {
-        const T four = (T)4, two = (T)2;
-        const bool fluid = fl & FL_SELF_FLUID;
+    // The 13-point neighbourhood of the carrying velocity around a cell: from the staged planes (the step), or from
+    // memory (the general path, which runs after the march, when the planes are gone).
+    struct Nbh {
+        T u_c, u_xp, u_ym, u_xp_ym, u_zm, u_xp_zm, v_c, v_xm, v_yp, v_xm_yp, v_zm, v_yp_zm, w_c, w_xm, w_zp, w_xm_zp, w_ym, w_ym_zp;
+    };
+    auto nbh_staged = [&](int z) -> Nbh {
         const T* Uc = plane(VF + 0, z) + wl; const T* Uzm = plane(VF + 0, z - 1) + wl;
         const T* Vc = plane(VF + 1, z) + wl; const T* Vzm = plane(VF + 1, z - 1) + wl;
         const T* Wc = plane(VF + 2, z) + wl; const T* Wzp = plane(VF + 2, z + 1) + wl;
-        const T u_c = Uc[0], u_xp = Uc[1], u_ym = Uc[-WX], u_xp_ym = Uc[1 - WX], u_zm = Uzm[0], u_xp_zm = Uzm[1];
-        const T v_c = Vc[0], v_xm = Vc[-1], v_yp = Vc[WX], v_xm_yp = Vc[WX - 1], v_zm = Vzm[0], v_yp_zm = Vzm[WX];
-        const T w_c = Wc[0], w_xm = Wc[-1], w_zp = Wzp[0], w_xm_zp = Wzp[-1], w_ym = Wc[-WX], w_ym_zp = Wzp[-WX];
+        return Nbh{Uc[0], Uc[1], Uc[-WX], Uc[1 - WX], Uzm[0], Uzm[1], Vc[0], Vc[-1], Vc[WX], Vc[WX - 1], Vzm[0], Vzm[WX],
+                   Wc[0], Wc[-1], Wzp[0], Wzp[-1], Wc[-WX], Wzp[-WX]};
+    };
+    auto nbh_memory = [&](int z) -> Nbh {   // (an interior cell: every neighbour exists)
+        const OFF i = (((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x) * (OFF)sizeof(T);
+        const OFF e = (OFF)sizeof(T);
+        const T *Um = src[VF + 0], *Vm = src[VF + 1], *Wm = src[VF + 2];
+        return Nbh{*at_byte(Um, i), *at_byte(Um, i + e), *at_byte(Um, i - sy), *at_byte(Um, i + e - sy), *at_byte(Um, i - sz), *at_byte(Um, i + e - sz),
+                   *at_byte(Vm, i), *at_byte(Vm, i - e), *at_byte(Vm, i + sy), *at_byte(Vm, i + sy - e), *at_byte(Vm, i - sz), *at_byte(Vm, i + sy - sz),
+                   *at_byte(Wm, i), *at_byte(Wm, i - e), *at_byte(Wm, i + sz), *at_byte(Wm, i + sz - e), *at_byte(Wm, i - sy), *at_byte(Wm, i - sy + sz)};
+    };
+    // One interior cell: the three velocity samples and the density sample around the neighbourhood nb.
+    // `smp(f, dx, dy, dz)` is the sampler; `first` says that this is the cell's first pass.
+    auto cell = [&](auto&& smp, const Nbh& nb, uint32_t fl, bool first, T& nu, T& nv, T& nw, T& nd) -> T {
+        const T four = (T)4, two = (T)2;
+        const bool fluid = fl & FL_SELF_FLUID;
+        const T u_c = nb.u_c, u_xp = nb.u_xp, u_ym = nb.u_ym, u_xp_ym = nb.u_xp_ym, u_zm = nb.u_zm, u_xp_zm = nb.u_xp_zm;
+        const T v_c = nb.v_c, v_xm = nb.v_xm, v_yp = nb.v_yp, v_xm_yp = nb.v_xm_yp, v_zm = nb.v_zm, v_yp_zm = nb.v_yp_zm;
+        const T w_c = nb.w_c, w_xm = nb.w_xm, w_zp = nb.w_zp, w_xm_zp = nb.w_xm_zp, w_ym = nb.w_ym, w_ym_zp = nb.w_ym_zp;
         if (first && res_part) {   // the cells and the value of k_div_sumsq
             const uint32_t movable = (fl & FL_SELF_FLUID) ? (fl & FL_NBR) : (fl & (FL_XP | FL_YP | FL_ZP));
             if (relaxes(fl) && movable) {
@@ -279,18 +297,27 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             const uint32_t dAB = sA - sB, dBC = sB - sC;
             const uint32_t zedge = (gz == 1 ? 1u : 0u) | (gz == g.gnz - 2 ? 2u : 0u);
             const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, zedge, sB, sC, dAB, dBC, bad); },
-                               z, fl, true, nu, nv, nw, nd);
+                               nbh_staged(z), fl, true, nu, nv, nw, nd);
             bad = bad || !isfinite(chk);
         }
         res[0] = nu; res[1] = nv; res[2] = nw; res[3] = nd;
         return bad;
     };
-    // The same location by the general path (rare: the neighbourhood is read again rather than kept in registers).
-    auto compute_general = [&](int z, uint32_t fl, T (&res)[4]) {
+    // The same location by the general path, after the march (rare): everything comes from memory, the cell's own
+    // carried values as the staging formed them.
+    auto compute_general = [&](int z, T (&res)[4]) {
         const int gz = z + g.gz0;
-        T nu = plane(0, z)[wl], nv = plane(1, z)[wl], nw = plane(2, z)[wl], nd = plane(3, z)[wl];
+        const OFF i = (((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x) * (OFF)sizeof(T);
+        const uint32_t fl = flags[((OFF)z * (OFF)g.ny + (OFF)y) * (OFF)g.nx + (OFF)x];
+        T own[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            own[f] = *at_byte(src[f], i);
+            if (REFL && f < 3) own[f] = (T)2 * *at_byte(src[4 + f], i) - own[f];
+        }
+        T nu = own[0], nv = own[1], nw = own[2], nd = own[3];
         bool oob_v = false, oob_d = false;
-        cell([&](int f, T dx, T dy, T dz) { return slow_sample(f, dx, dy, dz, gz, f == 3 ? oob_d : oob_v); }, z, fl, false, nu, nv, nw, nd);
+        cell([&](int f, T dx, T dy, T dz) { return slow_sample(f, dx, dy, dz, gz, f == 3 ? oob_d : oob_v); }, nbh_memory(z), fl, false, nu, nv, nw, nd);
         if (SLAB) {
             const bool oob = ((fl & FL_SELF_FLUID) && oob_v) || (!(fl & FL_SELF_OBJECT) && oob_d);
             if (oob) *oob_flag = 1;
@@ -311,6 +338,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         }
     };
 
+    uint32_t again[4] = {0u, 0u, 0u, 0u};   // planes of this chunk (at most 128: kMaxChunk) whose cell goes to the general path
     for (int p = c0 - R; p <= c0 + R; ++p) { fetch(p); commit(p); }
     __syncthreads();
     for (int z = c0; z < c1; ++z) {
@@ -329,13 +357,29 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
             else if (safe_x && safe_z) bad = compute(AdvSafe<true, false, true>{}, z, fl, res);
             else if (safe_x && safe_y) bad = compute(AdvSafe<true, true, false>{}, z, fl, res);
             else bad = compute(AdvSafe<false, false, false>{}, z, fl, res);
-            if (__builtin_expect(bad, 0)) compute_general(z, fl, res);
+            // a cell that the step could not serve is computed again after the march (its plane is noted; what the step
+            // made of it is stored meanwhile and overwritten then): the general path, large and rare, stays out of the loop
+            if (__builtin_expect(bad, 0)) {
+                const int k = z - c0;
+                again[0] |= k < 32 ? 1u << k : 0u;
+                again[1] |= k >= 32 && k < 64 ? 1u << (k - 32) : 0u;
+                again[2] |= k >= 64 && k < 96 ? 1u << (k - 64) : 0u;
+                again[3] |= k >= 96 ? 1u << (k - 96) : 0u;
+            }
         }
         commit(z + R + 1);     // into the slot of plane z-R-1, which no wave reads any more
         asm volatile("" ::: "memory");
         if (mine) store(z, res);
         __syncthreads();
     }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        for (uint32_t m = again[kk]; m; m &= m - 1) {
+            const int z = c0 + 32 * kk + (__ffs(m) - 1);
+            T res[4];
+            compute_general(z, res);
+            store(z, res);
+        }
     if (res_part) {   // one partial per workgroup, added in a fixed order
         double* red = reinterpret_cast<double*>(lds_raw);
         racc = wave_sum(racc);

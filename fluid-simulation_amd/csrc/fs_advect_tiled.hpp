@@ -173,7 +173,7 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
     // sB, sC = byte offsets of the ring slots of planes z, z+1; dAB, dBC = slot(z-1) - slot(z), slot(z) - slot(z+1)
     // (uniform over the workgroup); zedge: bit 0 = the plane is gz == 1, bit 1 = it is gz == gnz-2
     auto lds_sample = [&](auto safe_tag, int f, T dx, T dy, T dz, T zf, uint32_t zedge, uint32_t sB, uint32_t sC, uint32_t dAB,
-                          uint32_t dBC, bool& bad) -> T {
+                          uint32_t dBC, T& reach) -> T {
         using S = decltype(safe_tag);
         const T one = (T)1;
         const T dxt = dx * tv, dyt = dy * tv, dzt = dz * tv;
@@ -182,7 +182,9 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         const T fu = px - bx, fv = py - by, fw = pz - bz;
         FastTrace<T, OFF> tr;
         tr.x0 = one - fu; tr.x1 = fu; tr.y0 = one - fv; tr.y1 = fv; tr.z0 = one - fw; tr.z1 = fw;
-        const bool in = fmax(fmax(fabs(dxt), fabs(dyt)), fabs(dzt)) < lim;   // (false for a NaN)
+        // the largest displacement of the cell's samples so far; the caller compares it with the bound once.  (A
+        // maximum skips a NaN: a sample with one has a NaN result, which the caller's test of the results finds.)
+        reach = fmax(fmax(reach, fabs(dxt)), fmax(fabs(dyt), fabs(dzt)));
         // floor(p) - own coordinate is -1 or 0 per axis inside the window; the masks are all ones or zero whatever
         // the value, so the address stays inside the window for every lane
         const uint32_t mx = sign_mask(bx - xf), my = sign_mask(by - yf), mz = sign_mask(bz - zf);
@@ -204,7 +206,6 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
         t.s[4] = p0[WX + 1]; t.s[5] = p1[1]; t.s[6] = p1[WX]; t.s[7] = p1[WX + 1];
         T r = fast_combine(tr, t);
         asm volatile("" : "+v"(r));   // (keeps the sums of two samples from being zipped into packed additions, which costs moves and saves nothing)
-        bad = bad || !in;
         return r;
     };
     // the general path: the sample of the direct kernel
@@ -296,9 +297,10 @@ k_advect_tiled(Grid g, const T* __restrict__ qu, const T* __restrict__ qv, const
                            sC = (uint32_t)((z + 1) & (NPL - 1)) * PS * ESZ;
             const uint32_t dAB = sA - sB, dBC = sB - sC;
             const uint32_t zedge = (gz == 1 ? 1u : 0u) | (gz == g.gnz - 2 ? 2u : 0u);
-            const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, zedge, sB, sC, dAB, dBC, bad); },
+            T reach = 0;
+            const T chk = cell([&](int f, T dx, T dy, T dz) { return lds_sample(safe_tag, f, dx, dy, dz, zf, zedge, sB, sC, dAB, dBC, reach); },
                                nbh_staged(z), fl, true, nu, nv, nw, nd);
-            bad = bad || !isfinite(chk);
+            bad = !(reach < lim) || !isfinite(chk);
         }
         res[0] = nu; res[1] = nv; res[2] = nw; res[3] = nd;
         return bad;

@@ -8,6 +8,7 @@
 //               the sweep kernels (tile rows contiguous: ROWS x 2 KiB per plane and field); workgroups numbered
 //               tile-major (all tiles of a z-chunk, then the next chunk) as the kernels number them
 //   march-pm    the same with short chunks numbered so that the launch advances plane by plane
+//   march-1   the march on ONE array per generation whose rows alternate between the three fields
 // Build: hipcc --offload-arch=gfx950 -O3 stream_shapes.hip -o stream_shapes
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -53,6 +54,36 @@ __global__ void __launch_bounds__(1024) k_march(const f4* __restrict__ a, const 
     }
 }
 
+// the same march on ONE array per generation in which the rows of the three fields alternate (row y of u, of v, of w,
+// then row y + 1 of u ...): one input and one output stream, each tile row 3 x 2 KiB contiguous
+template <int NT>
+__global__ void __launch_bounds__(1024) k_march_rows_interleaved(const f4* __restrict__ a, f4* __restrict__ x, int n, int rows, int zc, int ntiles) {
+    const int tile = blockIdx.x % ntiles, chunk = blockIdx.x / ntiles;
+    const int row = tile * rows + threadIdx.y;
+    if (row >= n) return;
+    const size_t row4 = n / 4, plane4 = (size_t)n * 3 * row4;
+    size_t i = (size_t)chunk * zc * plane4 + (size_t)row * 3 * row4 + threadIdx.x;
+    const int zend = min(zc, n - chunk * zc);
+    f4 p[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p[k] = a[i + k * 64];
+    for (int kz = 0; kz < zend; ++kz) {
+        const size_t j = i + plane4;
+        f4 q[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = p[k];
+        if (kz + 1 < zend) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) q[k] = a[j + k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { if (NT) __builtin_nontemporal_store(p[k], x + i + k * 64); else x[i + k * 64] = p[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = q[k];
+        i = j;
+    }
+}
+
 int main() {
     const int n = 512;
     const size_t cells = (size_t)n * n * n, bytes = cells * 4, n4 = cells / 4;
@@ -87,6 +118,18 @@ int main() {
                 snprintf(name, sizeof name, "march, tile %2d rows x 512, %3d planes per workgroup, non-temporal stores", rows, zc);
                 timeit([&] { hipLaunchKernelGGL((k_march<1>), dim3(ntiles * chunks), dim3(64, rows), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], n, rows, zc, ntiles); }, name);
             }
+        }
+    }
+    // the three fields as alternating rows of one array: f[0..2] and f[3..5] are adjacent in the arena (with slack between them,
+    // which the interleaved kernels do not step over: they use the first 3 * bytes of each half)
+    for (int rows : {16, 8}) {
+        const int ntiles = (n + rows - 1) / rows;
+        for (int zc : {128, 64, 32, 16}) {
+            const int chunks = (n + zc - 1) / zc;
+            snprintf(name, sizeof name, "march, rows of u, v, w alternating in ONE array, tile %2d rows, %3d planes per workgroup", rows, zc);
+            timeit([&] { hipLaunchKernelGGL((k_march_rows_interleaved<0>), dim3(ntiles * chunks), dim3(64, rows), 0, 0, (const f4*)arena, (f4*)(arena + 3 * (bytes + slack)), n, rows, zc, ntiles); }, name);
+            snprintf(name, sizeof name, "  the same, non-temporal stores");
+            timeit([&] { hipLaunchKernelGGL((k_march_rows_interleaved<1>), dim3(ntiles * chunks), dim3(64, rows), 0, 0, (const f4*)arena, (f4*)(arena + 3 * (bytes + slack)), n, rows, zc, ntiles); }, name);
         }
     }
     hipFree(arena);

@@ -171,6 +171,42 @@ def test_semi_lagrange_displacements_around_one_cell(fsamd, dtype):
         assert_fields_equal(o, g, what=f"displacements around one cell, pass {it}")
 
 
+def test_general_path_in_every_part_of_a_chunk_of_128_planes(fsamd):
+    """The staged kernel notes the planes whose cell has to be computed again by the general path in a mask of 128 bits
+    and works them off after its march.  A workgroup is given that many planes only where the tiles of a plane fill
+    the GPU (512 x 512 cells here: one chunk of 128 planes), so the small grids of the other tests touch the first
+    bits only.  Cells with displacements of several cells, a NaN and infinities, in the first, last and boundary
+    planes of every 32-bit word of the mask; the direct kernel (checked against the oracle elsewhere) is the reference."""
+    nx, ny, nz = 512, 512, 128
+    rng = np.random.default_rng(77)
+    fields = []
+    for k in range(4):
+        f = np.zeros((nz, ny, nx), dtype=np.float32)
+        f[1:-1, 1:-1, 1:-1] = (rng.random((nz - 2, ny - 2, nx - 2), dtype=np.float32) * 2 - 1) * (0.4 if k < 3 else 1.0)
+        fields.append(f)
+    planes = [1, 30, 31, 32, 33, 62, 63, 64, 65, 94, 95, 96, 97, 125, 126]
+    for n, z in enumerate(planes):
+        y, x = 3 + 37 * n % 500, 5 + 53 * n % 500
+        fields[n % 3][z, y, x] = (-1.0) ** n * (7.0 + n)             # several cells per half step
+        fields[(n + 1) % 3][z, (y + 200) % 510 + 1, (x + 100) % 510 + 1] = 3.0e9 if n % 2 else -np.inf
+        fields[3][z, (y + 100) % 510 + 1, (x + 300) % 510 + 1] = np.nan
+    sims = []
+    for kernel in (0, 1):
+        g = fsamd.FluidSim3D(nx, ny, nz, advect_kernel=kernel, step_mode=1, stop_mode=fsamd.STOP_FIXED, max_iters=1)
+        for k in range(4):
+            g.set_field(k, fields[k])
+        sims.append(g)
+    for what in ("semi_lagrange", "advance"):
+        for g in sims:
+            g.semi_lagrange(0.5) if what == "semi_lagrange" else g.advance(0.25)
+        for k in range(4):
+            a, b = sims[0].get_field(k), sims[1].get_field(k)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (what, k)
+            assert np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0)), (what, k)
+    for g in sims:
+        g.close()
+
+
 def test_semi_lagrange_rows_longer_than_8192(fsamd):
     # beyond 8192 cells per axis a 4-byte coordinate minus a displacement below one cell may round across a cell
     # boundary: the staged kernel then serves no sample from its window, and the result is still the oracle's

@@ -332,10 +332,48 @@ int exchange_halos(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st =
     return rc;
 }
 
+// Up to kCopyBatch device-to-device copies in one launch: the halo planes of local slabs.  (An exchange between the
+// slabs of one process is 2 copies per interface and field - 42 for eight slabs and three fields - and as many calls
+// of hipMemcpyAsync take 6 us each on their stream, whatever they move.)
+constexpr int kCopyBatch = 48;
+struct CopyBatch { const char* src[kCopyBatch]; char* dst[kCopyBatch]; size_t bytes[kCopyBatch]; };
+
+__global__ void __launch_bounds__(256) k_copy_batch(CopyBatch b) {
+    const char* src = b.src[blockIdx.y];
+    char* dst = b.dst[blockIdx.y];
+    const size_t bytes = b.bytes[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    if ((((uintptr_t)src | (uintptr_t)dst | bytes) & 15u) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = tid; i < bytes / 16; i += nthreads) d4[i] = s4[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += nthreads) dst[i] = src[i];
+    }
+}
+
 int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t st) {
     // Planes at distance [d0, d1) from an interface: the owned planes H + d (below: H + own - 1 - d) of a part fill
     // the halo planes H + own + d (H - 1 - d) of its lower (upper) neighbour.  All parts hold the same H.
     bool remote = false;
+    CopyBatch batch;
+    int queued = 0;
+    size_t largest = 0;
+    auto flush = [&]() -> int {
+        if (queued == 0) return FS_OK;
+        const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>(largest / (16 * 256 * 4), 1), 256);
+        hipLaunchKernelGGL(k_copy_batch, dim3(blocks, queued, 1), dim3(256), 0, st, batch);
+        SIM_HIP(hipGetLastError());
+        queued = 0;
+        largest = 0;
+        return FS_OK;
+    };
+    auto copy = [&](char* dst, const char* src, size_t bytes) -> int {
+        batch.dst[queued] = dst; batch.src[queued] = src; batch.bytes[queued] = bytes;
+        largest = std::max(largest, bytes);
+        if (++queued == kCopyBatch) return flush();
+        return FS_OK;
+    };
     for (Part& p : s->parts) {
         const ptrdiff_t H = p.H, own = p.own_planes();
         for (const HaloOp& op : ops) {
@@ -346,14 +384,13 @@ int exchange_halos_impl(fs3d_sim* s, const std::vector<HaloOp>& ops, hipStream_t
             if (p.has_hi && (&p != &s->parts.back())) {
                 Part& q = *(&p + 1);
                 char* theirs = (char*)op.base(s, q, op.which);
-                SIM_HIP(hipMemcpyAsync(theirs + (H - d1) * plane, mine + (H + own - d1) * plane, (size_t)((d1 - d0) * plane),
-                                       hipMemcpyDeviceToDevice, st));
-                SIM_HIP(hipMemcpyAsync(mine + (H + own + d0) * plane, theirs + (H + d0) * plane, (size_t)((d1 - d0) * plane),
-                                       hipMemcpyDeviceToDevice, st));
+                FS_TRY(copy(theirs + (H - d1) * plane, mine + (H + own - d1) * plane, (size_t)((d1 - d0) * plane)));
+                FS_TRY(copy(mine + (H + own + d0) * plane, theirs + (H + d0) * plane, (size_t)((d1 - d0) * plane)));
             }
         }
         if ((p.has_lo && &p == &s->parts.front()) || (p.has_hi && &p == &s->parts.back())) remote = true;
     }
+    FS_TRY(flush());
     if (!remote || s->nranks == 1) return FS_OK;
     Rccl* R = s->rccl;
     FS_TRY(nccl_check(s, R->GroupStart(), "ncclGroupStart"));

@@ -347,6 +347,10 @@ __global__ void __launch_bounds__(256) k_copy_batch(CopyBatch b) {
         const uint4* s4 = reinterpret_cast<const uint4*>(src);
         uint4* d4 = reinterpret_cast<uint4*>(dst);
         for (size_t i = tid; i < bytes / 16; i += nthreads) d4[i] = s4[i];
+    } else if ((((uintptr_t)src | (uintptr_t)dst | bytes) & 3u) == 0) {   // (planes of an odd number of 4-byte cells)
+        const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+        for (size_t i = tid; i < bytes / 4; i += nthreads) d1[i] = s1[i];
     } else {
         for (size_t i = tid; i < bytes; i += nthreads) dst[i] = src[i];
     }

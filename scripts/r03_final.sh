@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 closing run: the GPU suite, the bench lines that DESIGN quotes, the kernel statistics under rocprofv3.
+# Closing run: the GPU suite, the bench lines of the default and the longer window, the kernel statistics under rocprofv3.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; mkdir -p $OUT; cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 first GPU call: the GPU test suite, the fixed-point experiment, the copy yardstick, MacCormack kernel statistics.
+# One GPU call: the GPU test suite, the fixed-point experiment, the copy yardstick, MacCormack kernel statistics.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r03a
